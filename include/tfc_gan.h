@@ -1,0 +1,132 @@
+/*
+ * tfc_gan.h -- C ABI of libtfcgan_hip.so: the MI355X (gfx950) kernels of the TFC-GAN PATCH-16 training hot path.
+ *
+ * The reference (nudro/TFC-GAN) has NO native or FFI layer: its hot path is the PyTorch op sequence inside
+ * TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py ("P16" below), lines 545-638.  Each entry point here replaces one
+ * stock-op sequence of that script; the host-side mirror of the reference's Python surface (GeneratorUNet,
+ * Discriminator1, make_16_patches, ...) lives in tfc-gan_amd/ and binds these symbols with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named *_host; `stream` is a hipStream_t passed as void* (0 = null stream);
+ *   - activations are NHWC with an explicit pixel pitch (elements), dtype `dt` (TFC_DT_BF16 storage / fp32 accumulate,
+ *     or TFC_DT_F32 = exact-fp32 parity mode using v_mfma_f32_32x32x2_f32); channel counts that are gathered or
+ *     produced by MFMA tiles are padded to a multiple of 8 by the caller (3 -> 8, 6 -> 8, 1 -> 8);
+ *   - weights / gradients / statistics / losses are fp32 in the torch layouts of the reference's state_dict;
+ *   - return value 0 = success, otherwise a negative code; tfc_last_error() gives the thread-local message.
+ *     No entry point allocates, frees or synchronises (all are hipGraph-capturable).
+ */
+#ifndef TFC_GAN_H
+#define TFC_GAN_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFC_DT_BF16 0
+#define TFC_DT_F32 1
+
+/* convolution ops of the path */
+#define TFC_OP_CONV 0     /* nn.Conv2d(k4,s1,p1)                              P16:105 (UNetDown), :189 (Discriminator1 blocks) */
+#define TFC_OP_PADCONV 1  /* nn.ZeroPad2d((1,0,1,0)) + nn.Conv2d(k4,p1)       P16:201-202 (PatchGAN head)                    */
+#define TFC_OP_CONVT 2    /* nn.ConvTranspose2d(k4,s2,p1)                     P16:122 (UNetUp)                               */
+#define TFC_OP_UPCONV 3   /* nn.Upsample(x2)+nn.ZeroPad2d((1,0,1,0))+nn.Conv2d(k4,p1) [+Tanh]   P16:153-158 (generator head)  */
+
+/* epilogue flags of tfc_conv_fwd / tfc_conv_dgrad */
+#define TFC_EP_BIAS 1       /* + bias[Cout]                                                                                   */
+#define TFC_EP_STATS 2      /* stats[N][Cout][2] += (sum, sum of squares) of the result: nn.InstanceNorm2d statistics, P16:107 */
+#define TFC_EP_ACCUM 4      /* result += existing output (skip-connection gradient accumulation, torch.cat backward P16:133)  */
+#define TFC_EP_TANH_NCHW 8  /* nn.Tanh (P16:157) and store fp32 NCHW to `out_nchw`                                            */
+
+const char* tfc_last_error(void);
+int tfc_abi_version(void);
+
+/* ---- weights ------------------------------------------------------------------------------------------------- */
+/* pass: 0 = forward operand stream, 1 = dgrad operand stream.  w is the torch-layout fp32 weight
+ * (Conv2d [Cout][Cin][4][4]; ConvTranspose2d [Cin][Cout][4][4]); *scale (nullable device scalar) multiplies every
+ * element (1/sigma of spectral_norm, P16:188).  Replaces the implicit weight cast of torch.cuda.amp.autocast. */
+size_t tfc_conv_packed_bytes(int dt, int op, int pass, int Cin, int Cout);
+int tfc_conv_pack(void* stream, int dt, int op, int pass, const float* w, const float* scale, void* packed, int Cin, int Cout);
+
+/* ---- forward: y = op(x) ; x: [N][H][W][x_pitch], y: [N][OH][OW][y_pitch] (OH = H-1 | H | 2H | 2H) ---------------- */
+int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
+                 const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, int flags);
+/* ---- input gradient: dx = op^T(dy) (flags: TFC_EP_ACCUM) -------------------------------------------------------- */
+int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
+                   const void* packed, void* dx, int dx_pitch, int flags);
+/* ---- weight gradient: dw (torch layout, fp32) = or += x (*) dy ; ws: tfc_conv_wgrad_ws_bytes() scratch ----------- */
+size_t tfc_conv_wgrad_ws_bytes(int op, int Cin, int Cout);
+int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, const void* dy, int dy_pitch, int N, int H, int W,
+                   int Cin, int Cout, void* ws, float* dw, int accumulate);
+
+/* ---- fused normalisation / activation / anti-aliased pooling ------------------------------------------------------
+ * forward  : y = Dropout( Blur_{pool}( Act_{slope}( norm ? InstanceNorm(x; stats) : x ) ) )      P16:106-111, :123-128, :191-192
+ *   pool: 0 none, 1 antialiased_cnns.BlurPool(stride=1), 2 BlurPool(stride=2) (reflect pad 1/2, [1,3,3,1]^2/64)
+ *   slope: 0.2 LeakyReLU, 0 ReLU, 1 identity; stats: [N][C][2] (sum, sumsq) of x over H*W; eps 1e-5, biased variance
+ *   stats_out (nullable): [N][C][2] += (sum, sumsq) of y  (InstanceNorm that FOLLOWS the blur in UNetUp)
+ *   dropout: drop_p in [0,1): counter-based mask of (seed, element index), identical in forward and backward
+ * backward : mode 0: dx = g'            (norm == 0)
+ *            mode 1: rstats[N][C][2] += (sum g', sum g' * xhat)          (InstanceNorm backward, reduction phase)
+ *            mode 2: dx = rstd * (g' - mean g' - xhat * mean(g' xhat))   (apply phase)
+ *            g' = Blur^T(dropmask * dy) * Act'(xhat) ; x == NULL => Act' = 1
+ */
+int tfc_act_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* stats, int norm,
+                float slope, int pool, float drop_p, uint32_t seed, void* y, int y_pitch, float* stats_out);
+int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int dy_pitch, const void* x, int x_pitch, int N, int H, int W, int C,
+                const float* stats, int norm, float slope, int pool, float drop_p, uint32_t seed, float* rstats, void* dx, int dx_pitch);
+int tfc_dropout_mask(void* stream, uint8_t* keep, long long n, float drop_p, uint32_t seed);   /* test hook: the mask itself */
+
+/* ---- layout plumbing at the NCHW fp32 module boundary -------------------------------------------------------------- */
+int tfc_pack_nhwc8(void* stream, int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int H, int W);   /* torch.cat((a,b),1), P16:207 */
+int tfc_unpack_nchw(void* stream, int dt, const void* in, int pitch, int c0, int C, float* out, int N, int H, int W, float alpha, float beta);
+int tfc_tanh_bwd_pack(void* stream, int dt, const float* g, const float* y, void* dyraw, float* dbias, int N, int C, int H, int W);
+int tfc_colsum(void* stream, int dt, const void* x, long long rows, int pitch, int C, float* out);   /* bias gradient (out += ) */
+int tfc_cast(void* stream, int dt, int to_f32, const void* x, void* y, long long n);
+int tfc_axpby(void* stream, float* out, const float* x, const float* y, long long n, float a, float b);
+
+/* ---- spectral norm: torch.nn.utils.parametrizations.spectral_norm, P16:188 ---------------------------------------- */
+/* W: [R][K] fp32; u[R], v[K] updated in place when power_iter != 0; sigma2 = {sigma, 1/sigma}; ws: (R+K) floats */
+int tfc_spectral_norm_step(void* stream, const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter);
+/* gW_orig (=/+=) (G - <G, W/sigma> u v^T) / sigma ; ws: 1 float */
+int tfc_spectral_norm_bwd(void* stream, const float* G, const float* W, const float* u, const float* v, const float* sigma2,
+                          float* ws, float* gout, int R, int K, int accumulate);
+
+/* ---- loss heads --------------------------------------------------------------------------------------------------- */
+/* 16-patch triplet ("contrastive") head: make_16_patches P16:227-253 + nn.TripletMarginLoss(margin=1,p=2) P16:75 applied
+ * 16x with negatives real-patch[neg_idx_host[k]] P16:562-583.  fake/real: fp32 NCHW [N][C][256][256].
+ * loss[0] = (1/16) sum_k mean(...);  dfake (nullable) = gscale * d loss / d fake. */
+int tfc_patch16_triplet(void* stream, const float* fake, const float* real, const int* neg_idx_host, int N, int C,
+                        float* loss, float* dfake, float gscale);
+/* spectra: ToPILImage -> convert("L") -> np.fft.rfft2 -> fftshift -> abs / arctan2, P16:271-319.
+ * img: fp32 [N][C][rows][rs] window grid: S in {64,256}; windows per image = wins_x*wins_y tiles of S x S starting at the
+ * image origin; amp/pha: [N*wins][S][S/2+1] fp32; shift != 0 applies np.fft.fftshift to both axes. */
+int tfc_fft_spectrum(void* stream, const float* img, long long batch_stride, long long chan_stride, int row_stride, int C, int S,
+                     int wins_x, int wins_y, int N, float* amp, float* pha, int shift);
+/* out[0] (=/+=) scale * sum |a-b| : nn.L1Loss pieces of calculate_ffts, P16:323-375 */
+int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first);
+/* relativistic BCEWithLogits, P16:554 (mode 0) and P16:628-630 (mode 1); a,b: n logits in dt, `stride` elements apart
+ * (the PatchGAN head stores its single channel at pixel pitch 8); loss fp32 scalar; da/db (nullable) = gscale * dloss */
+int tfc_bce_relativistic(void* stream, int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode,
+                         float* loss, void* da, void* db, float gscale);
+/* torch.optim.Adam step (P16:461-462) on flat fp32 buffers; step >= 1; gscale multiplies the gradient (1/world size) */
+int tfc_adam_step(void* stream, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                  int step, float gscale);
+
+/* ---- measurement -------------------------------------------------------------------------------------------------- */
+/* When enabled every gather-GEMM / wgrad launch is bracketed by hipEvents on its own stream; tfc_prof_collect()
+ * (call after synchronising) sums them per kernel class: 0 = tfc_igemm_kernel, 1 = tfc_wgrad_kernel. */
+int tfc_prof_enable(int on);
+int tfc_prof_collect(int kclass, double* total_ms, double* algorithmic_flop, long long* launches);
+
+/* ---- test hooks (host side, no GPU): the table-driven gather model evaluated on the CPU with the SAME descriptors and
+ * the SAME packed operand stream the kernels consume.  Never called by the product path. */
+int tfc_host_emulate_conv(int op, int pass, int elem_size, const float* x_host, const float* w_host, float* y_host,
+                          int N, int H, int W, int Cin, int Cout);   /* pass 2 = wgrad: w_host is dy, y_host is dw */
+/* device probe of the MFMA / transposing-read lane maps the kernels rely on (writes 3*64*16 floats) */
+int tfc_probe_mfma(void* stream, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,137 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every declared symbol, and the table-driven
+gather model (descriptors + packed operand stream, evaluated by the library's host emulator) reproduces torch's
+convolutions for every op / pass of the path -- conv, pad+conv, transposed conv, upsample+pad+conv; fwd, dgrad, wgrad."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import tfc_gan_amd as T
+from tfc_gan_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "tfc_gan.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tfc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 28
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.tfc_abi_version() == 1
+
+
+def test_errors_are_loud():
+    lib = _lib.load()
+    rc = lib.tfc_conv_fwd(None, 7, 0, None, 0, 1, 8, 8, 8, 8, None, None, 0, None, None, None, 0)
+    assert rc != 0 and b"dtype" in lib.tfc_last_error()
+    with pytest.raises(T.TfcError):
+        _lib.check(rc, "tfc_conv_fwd")
+    with pytest.raises(T.TfcError):                      # CPU tensors are refused, never silently computed elsewhere
+        T.ops.pack_nhwc8(T.ops.DT_BF16, torch.zeros(1, 3, 8, 8))
+
+
+def _ref(op, x, w):
+    if op == _lib.OP_CONV:
+        return F.conv2d(x, w, padding=1)
+    if op == _lib.OP_PADCONV:
+        return F.conv2d(F.pad(x, (1, 0, 1, 0)), w, padding=1)
+    if op == _lib.OP_CONVT:
+        return F.conv_transpose2d(x, w, stride=2, padding=1)
+    return F.conv2d(F.pad(F.interpolate(x, scale_factor=2), (1, 0, 1, 0)), w, padding=1)
+
+
+def _nhwc8(x):
+    n, c, h, w = x.shape
+    out = np.zeros((n, h, w, (c + 7) // 8 * 8), dtype=np.float32)
+    out[..., :c] = x.detach().numpy().transpose(0, 2, 3, 1)
+    return np.ascontiguousarray(out)
+
+
+def _emulate(op, pas, es, a, b, out_shape, N, H, W, Cin, Cout):
+    lib = _lib.load()
+    y = np.zeros(out_shape, dtype=np.float32)
+    rc = lib.tfc_host_emulate_conv(op, pas, es, a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                                   y.ctypes.data_as(ctypes.c_void_p), N, H, W, Cin, Cout)
+    _lib.check(rc, "tfc_host_emulate_conv")
+    return y
+
+
+CASES = [(_lib.OP_CONV, 2, 9, 19, 3, 16), (_lib.OP_CONV, 1, 20, 9, 32, 5), (_lib.OP_CONV, 1, 8, 8, 16, 40),
+         (_lib.OP_PADCONV, 2, 9, 17, 32, 1), (_lib.OP_CONVT, 2, 5, 9, 16, 8), (_lib.OP_CONVT, 1, 9, 17, 32, 16),
+         (_lib.OP_UPCONV, 1, 9, 10, 32, 3), (_lib.OP_UPCONV, 2, 8, 17, 16, 3)]
+
+
+@pytest.mark.parametrize("op,N,H,W,Cin,Cout", CASES)
+@pytest.mark.parametrize("es", [2, 4])
+def test_gather_model_matches_torch(op, N, H, W, Cin, Cout, es):
+    if (((Cin + 7) // 8 * 8) * es > 64 and (((Cin + 7) // 8 * 8) * es) % 64) or (((Cout + 7) // 8 * 8) * es > 64 and (((Cout + 7) // 8 * 8) * es) % 64):
+        pytest.skip("channel count not representable in this chunk geometry")
+    rng = np.random.default_rng(op * 100 + Cin)
+    x = torch.from_numpy(rng.standard_normal((N, Cin, H, W)).astype(np.float32)).requires_grad_(True)
+    wshape = (Cin, Cout, 4, 4) if op == _lib.OP_CONVT else (Cout, Cin, 4, 4)
+    w = torch.from_numpy((rng.standard_normal(wshape) * 0.1).astype(np.float32)).requires_grad_(True)
+    y = _ref(op, x, w)
+    go = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    gx, gw = torch.autograd.grad(y, (x, w), go)
+    OH, OW = y.shape[2:]
+    c8 = lambda c: (c + 7) // 8 * 8  # noqa: E731
+    wn = np.ascontiguousarray(w.detach().numpy())
+    # forward
+    got = _emulate(op, 0, es, _nhwc8(x), wn, (N, OH, OW, c8(Cout)), N, H, W, Cin, Cout)
+    np.testing.assert_allclose(got[..., :Cout], y.detach().numpy().transpose(0, 2, 3, 1), atol=2e-4)
+    # dgrad
+    got = _emulate(op, 1, es, _nhwc8(go), wn, (N, H, W, c8(Cin)), N, H, W, Cin, Cout)
+    np.testing.assert_allclose(got[..., :Cin], gx.numpy().transpose(0, 2, 3, 1), atol=2e-4)
+    # wgrad
+    got = _emulate(op, 2, es, _nhwc8(x), _nhwc8(go), wshape, N, H, W, Cin, Cout)
+    np.testing.assert_allclose(got, gw.numpy(), atol=2e-3, rtol=1e-4)
+
+
+def test_flat_params_and_buckets():
+    from tfc_gan_amd import nets, parallel
+    from oracle import tfcgan_oracle as O
+    G = O.GeneratorUNet((3, 256, 256))
+    named = {k: v for k, v in G.named_parameters()}
+    flat = parallel.FlatParams(named, nets.g_backward_order(), torch.device("cpu"))
+    assert flat.numel >= 29238275 and set(flat.order) == set(nets.g_param_names())
+    for k, p in named.items():
+        assert torch.equal(flat.views[k], p.detach()) and flat.views[k].data_ptr() % 16 == 0
+    red = parallel.BucketReducer(flat, bucket_bytes=32 << 20)
+    assert 2 <= len(red.buckets) <= 5
+    assert red.buckets[0][0] == 0 and red.buckets[-1][1] == flat.numel
+    assert all(a[1] == b[0] for a, b in zip(red.buckets, red.buckets[1:]))
+    assert red.finish() == 1.0
+    a, b = parallel.shared_neg_idx(3), parallel.shared_neg_idx(3)
+    assert a == b and len(a) == 16 and all(0 <= i < 16 for i in a) and a != parallel.shared_neg_idx(4)
+
+
+def test_patch_views_and_index_map(golden):
+    g = golden("patch_index_map")
+    B = torch.arange(3 * 256 * 256, dtype=torch.float32).reshape(1, 3, 256, 256)
+    ps = T.make_16_patches(B)
+    assert [int(p[0, 0, 0, 0]) for p in ps] == g["first_flat"].tolist()
+    assert [T.patch_first_flat_index(k) for k in range(16)] == g["first_flat"].tolist()
+    assert all(p.data_ptr() == B.data_ptr() + 4 * f for p, f in zip(ps, g["first_flat"].tolist()))    # views, no copies
+
+
+def test_module_state_dict_contract(golden):
+    g = golden("state_dict_keys")
+    G, D = T.GeneratorUNet((3, 256, 256)), T.Discriminator1((3, 256, 256))
+    assert list(G.state_dict().keys()) == g["g_keys"].tolist()
+    assert list(D.state_dict().keys()) == g["d_keys"].tolist()
+    assert [str(tuple(v.shape)) for v in G.state_dict().values()] == g["g_shapes"].tolist()
+    assert [str(tuple(v.shape)) for v in D.state_dict().values()] == g["d_shapes"].tolist()
+    G.apply(T.weights_init_normal)
+    D.apply(T.weights_init_normal)
+    assert abs(float(G.down2.model[0].weight.std()) - 0.02) < 2e-3
+    assert T.Discriminator is T.Discriminator1
+    with pytest.raises(T.TfcError):                      # CPU modules fail loudly: there is no CPU fallback
+        G(torch.zeros(1, 3, 256, 256))

@@ -1,0 +1,112 @@
+"""ctypes binding of libtfcgan_hip.so (C ABI declared in include/tfc_gan.h).
+
+The library is built in-tree with hipcc for gfx950 (``build()``); nothing here falls back to a CPU or PyTorch
+implementation: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libtfcgan_hip.so")
+SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "losses.hip", "probe.hip"]
+HEADERS = ["common.h", "tfc_desc.h", "pack_math.h"]
+PUBLIC_HEADER = os.path.join(_ROOT, "include", "tfc_gan.h")
+
+DT_BF16, DT_F32 = 0, 1
+OP_CONV, OP_PADCONV, OP_CONVT, OP_UPCONV = 0, 1, 2, 3
+EP_BIAS, EP_STATS, EP_ACCUM, EP_TANH_NCHW = 1, 2, 4, 8
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [PUBLIC_HEADER]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into tfc-gan_amd/libtfcgan_hip.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-Wl,-rpath,/opt/rocm/lib", "-o", SO_PATH + ".tmp"] + [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    return SO_PATH
+
+
+_c = ctypes
+_vp, _i, _f, _ll, _u32, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_longlong, _c.c_uint32, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/tfc_gan.h one to one
+PROTOTYPES = {
+    "tfc_last_error": (_c.c_char_p, []),
+    "tfc_abi_version": (_i, []),
+    "tfc_conv_packed_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "tfc_conv_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i]),
+    "tfc_conv_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i]),
+    "tfc_conv_dgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),
+    "tfc_conv_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
+    "tfc_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
+    "tfc_act_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _i, _vp]),
+    "tfc_act_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _vp, _i]),
+    "tfc_dropout_mask": (_i, [_vp, _vp, _ll, _f, _u32]),
+    "tfc_pack_nhwc8": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i]),
+    "tfc_unpack_nchw": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f]),
+    "tfc_tanh_bwd_pack": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "tfc_colsum": (_i, [_vp, _i, _vp, _ll, _i, _i, _vp]),
+    "tfc_cast": (_i, [_vp, _i, _i, _vp, _vp, _ll]),
+    "tfc_axpby": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f]),
+    "tfc_spectral_norm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    "tfc_spectral_norm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    "tfc_patch16_triplet": (_i, [_vp, _vp, _vp, _c.POINTER(_i), _i, _i, _vp, _vp, _f]),
+    "tfc_fft_spectrum": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
+    "tfc_l1_sum": (_i, [_vp, _vp, _vp, _ll, _f, _vp, _i]),
+    "tfc_bce_relativistic": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _f]),
+    "tfc_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f]),
+    "tfc_prof_enable": (_i, [_i]),
+    "tfc_prof_collect": (_i, [_i, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_ll)]),
+    "tfc_host_emulate_conv": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "tfc_probe_mfma": (_i, [_vp, _vp]),
+}
+
+
+def load():
+    """Load the shared object (building it when stale) and attach prototypes. torch must be imported first so that the
+    process already holds the HIP runtime torch ships; our library then binds to that same libamdhip64.so.7."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (HIP runtime first)
+        build()
+        lib = ctypes.CDLL(SO_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class TfcError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().tfc_last_error().decode("utf-8", "replace")
+        raise TfcError(f"libtfcgan_hip: {what} failed ({rc}): {msg}")

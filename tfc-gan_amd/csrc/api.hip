@@ -1,0 +1,600 @@
+// extern "C" surface of libtfcgan_hip.so (declared in include/tfc_gan.h): argument checking, gather-descriptor
+// construction for every convolution op / pass of the PATCH-16 path, launch, per-kernel timing hooks, and the
+// host-side emulator of the gather model used by the CPU tests.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/tfc_gan.h"
+#undef TFC_DT_BF16
+#undef TFC_DT_F32
+#undef TFC_EP_BIAS
+#undef TFC_EP_STATS
+#undef TFC_EP_ACCUM
+#undef TFC_EP_TANH_NCHW
+#include "tfc_desc.h"
+#include "pack_math.h"
+
+// ---- internal launchers (igemm.hip / elementwise.hip / losses.hip) ------------------------------------------
+int tfc_total_substeps(const TfcGather& d, int es);
+int tfc_nb32(int nout);
+int tfc_nb32_padded(int nout);
+size_t tfc_packed_bytes(const TfcGather& d, int es);
+hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
+hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, int flags, hipStream_t st);
+hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
+hipError_t tfc_launch_wgrad_finish(const float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
+hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st);
+hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats, void* dx, int use_x, int dx_pitch, hipStream_t st);
+hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, hipStream_t st);
+hipError_t tfc_launch_pack_nhwc8(int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int HW, hipStream_t st);
+hipError_t tfc_launch_unpack_nchw(int dt, const void* in, int pitch, int c0, int C, float* out, int N, int HW, float alpha, float beta, hipStream_t st);
+hipError_t tfc_launch_tanh_bwd_pack(int dt, const float* g, const float* y, void* out, float* dbias, int N, int C, int HW, hipStream_t st);
+hipError_t tfc_launch_sn_step(const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter, float eps, hipStream_t st);
+hipError_t tfc_launch_sn_bwd(const float* G, const float* W, const float* u, const float* v, const float* sigma2, float* dot_ws, float* gout, int R, int K, int accumulate, hipStream_t st);
+hipError_t tfc_launch_bce_rel(int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode, float* loss, void* da, void* db, float gscale, hipStream_t st);
+hipError_t tfc_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, hipStream_t st);
+hipError_t tfc_launch_axpby(float* out, const float* x, const float* y, long long n, float a, float b, hipStream_t st);
+hipError_t tfc_launch_dropout_mask(unsigned char* out, long long n, unsigned seed, unsigned thresh24, hipStream_t st);
+hipError_t tfc_launch_cast(int dt, int to_f32, const void* x, void* y, long long n, hipStream_t st);
+hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int* neg_idx, int N, int C, float margin, float eps, float* loss, float* dfake, float gscale, hipStream_t st);
+hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img, int nwin, float* amp, float* pha, int shift, hipStream_t st);
+hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st);
+hipError_t tfc_launch_probe(float* out, hipStream_t st);
+
+// ---- error handling --------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+static int hipfail(hipError_t e, const char* where) { return fail(-100 - (int)e, "%s: %s", where, hipGetErrorString(e)); }
+#define CHECK_HIP(expr, where) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hipfail(e_, where); } while (0)
+#define REQUIRE(cond, ...) do { if (!(cond)) return fail(-1, __VA_ARGS__); } while (0)
+
+extern "C" const char* tfc_last_error(void) { return g_err.c_str(); }
+extern "C" int tfc_abi_version(void) { return 1; }
+
+static inline int pad8(int c) { return (c + 7) / 8 * 8; }
+static inline int es_of(int dt) { return dt == TFC_DT_BF16 ? 2 : 4; }
+
+// ---- profiling: hipEvents around the two MFMA kernel classes ---------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int kclass; double flop; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+hipEvent_t get_event() {
+  if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  bool on;
+  hipStream_t st;
+  ProfRec rec;
+  ProfScope(int kclass, double flop, hipStream_t s) : st(s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    on = g_prof_on;
+    if (on) { rec.a = get_event(); rec.b = get_event(); rec.kclass = kclass; rec.flop = flop; hipEventRecord(rec.a, st); }
+  }
+  ~ProfScope() {
+    if (on) { hipEventRecord(rec.b, st); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(rec); }
+  }
+};
+}  // namespace
+
+extern "C" int tfc_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return 0;
+}
+extern "C" int tfc_prof_collect(int kclass, double* total_ms, double* flop, long long* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0, fl = 0;
+  long long n = 0;
+  std::vector<ProfRec> keep;
+  for (auto& r : g_prof) {
+    if (r.kclass != kclass) { keep.push_back(r); continue; }
+    float t = 0.f;
+    hipError_t e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hipfail(e, "tfc_prof_collect (synchronise before collecting)");
+    ms += t; fl += r.flop; ++n;
+    g_event_pool.push_back(r.a);
+    g_event_pool.push_back(r.b);
+  }
+  g_prof.swap(keep);
+  if (total_ms) *total_ms = ms;
+  if (flop) *flop = fl;
+  if (launches) *launches = n;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// descriptor construction.  (N,H,W,Cin,Cout) always describe the op's FORWARD input.
+//   pass 0 = forward, 1 = dgrad (source = dy, result = dx), 2 = wgrad (forward geometry, K = pixels)
+// ---------------------------------------------------------------------------------------------------------------
+struct WeightMap { int Nreal, Creal; long long sn, sc; };
+
+static int out_hw(int op, int h) { return op == TFC_OP_CONV ? h - 1 : (op == TFC_OP_PADCONV ? h : 2 * h); }
+static int num_phases(int op, int pass) { return ((op == TFC_OP_CONVT || op == TFC_OP_UPCONV) && pass != 1) ? 4 : 1; }
+
+static void set_tiles(TfcGather& d) {
+  d.tiles_y = (d.GH + TFC_TILE_H - 1) / TFC_TILE_H;
+  d.tiles_x = (d.GW + TFC_TILE_W - 1) / TFC_TILE_W;
+}
+
+// UPCONV: out[2a+p] reads source row a + off(p,k), off(0,.) = {-1,-1,0,0}, off(1,.) = {-1,0,0,1}
+static const int kUpOff[2][4] = {{-1, -1, 0, 0}, {-1, 0, 0, 1}};
+
+static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin, int Cout, int in_pitch, int out_pitch,
+                      TfcGather* dp, WeightMap* wm) {
+  TfcGather& d = *dp;
+  memset(&d, 0, sizeof d);
+  const int OH = out_hw(op, H), OW = out_hw(op, W);
+  d.nimg = N;
+  d.in_pitch = in_pitch;
+  d.out_pitch = out_pitch;
+  d.SS = 1; d.OS = 1; d.OOY = 0; d.OOX = 0;
+  d.nplanes = 1;
+  const int py = phase >> 1, px = phase & 1;
+  const bool fwd_geom = (pass != 1);
+  if (fwd_geom) {
+    d.IH = H; d.IW = W; d.Cin_pad = pad8(Cin);
+    d.OH = OH; d.OW = OW; d.Nout = Cout;
+    TfcPlane& p = d.plane[0];
+    switch (op) {
+      case TFC_OP_CONV:
+      case TFC_OP_PADCONV: {
+        const int o0 = (op == TFC_OP_CONV) ? -1 : -2;
+        d.GH = OH; d.GW = OW;
+        p.dy0 = o0; p.dx0 = o0; p.hh = 11; p.hw = 19; p.ntaps = 16;
+        for (int ky = 0; ky < 4; ++ky)
+          for (int kx = 0; kx < 4; ++kx) { const int t = ky * 4 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_slot[t] = t; }
+        if (wm) *wm = {Cout, Cin, (long long)Cin * 16, 16};
+        break;
+      }
+      case TFC_OP_CONVT: {
+        d.GH = H; d.GW = W; d.OS = 2; d.OOY = py; d.OOX = px;
+        p.dy0 = py - 1; p.dx0 = px - 1; p.hh = 9; p.hw = 17; p.ntaps = 4;
+        for (int jy = 0; jy < 2; ++jy)
+          for (int jx = 0; jx < 2; ++jx) {
+            const int t = jy * 2 + jx;
+            p.tap_dy[t] = 1 - jy; p.tap_dx[t] = 1 - jx;
+            p.tap_slot[t] = (1 - py + 2 * jy) * 4 + (1 - px + 2 * jx);
+          }
+        if (wm) *wm = {Cout, Cin, 16, (long long)Cout * 16};   // ConvTranspose2d weight [Cin][Cout][4][4]
+        break;
+      }
+      case TFC_OP_UPCONV: {
+        d.GH = H; d.GW = W; d.OS = 2; d.OOY = py; d.OOX = px;
+        p.dy0 = -1; p.dx0 = -1; p.hh = 10; p.hw = 18; p.ntaps = 16;
+        for (int ky = 0; ky < 4; ++ky)
+          for (int kx = 0; kx < 4; ++kx) {
+            const int t = ky * 4 + kx;
+            p.tap_dy[t] = kUpOff[py][ky] + 1; p.tap_dx[t] = kUpOff[px][kx] + 1; p.tap_slot[t] = t;
+          }
+        if (wm) *wm = {Cout, Cin, (long long)Cin * 16, 16};
+        break;
+      }
+      default: return fail(-1, "unknown op %d", op);
+    }
+  } else {
+    // dgrad: source = dy [N][OH][OW][Cout], result = dx [N][H][W][Cin]
+    d.IH = OH; d.IW = OW; d.Cin_pad = pad8(Cout);
+    d.OH = H; d.OW = W; d.Nout = Cin;
+    d.GH = H; d.GW = W;
+    switch (op) {
+      case TFC_OP_CONV:
+      case TFC_OP_PADCONV: {
+        TfcPlane& p = d.plane[0];
+        const int o0 = (op == TFC_OP_CONV) ? -2 : -1;
+        p.dy0 = o0; p.dx0 = o0; p.hh = 11; p.hw = 19; p.ntaps = 16;
+        for (int ky = 0; ky < 4; ++ky)
+          for (int kx = 0; kx < 4; ++kx) { const int t = ky * 4 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_slot[t] = (3 - ky) * 4 + (3 - kx); }
+        if (wm) *wm = {Cin, Cout, 16, (long long)Cin * 16};    // Conv2d weight [Cout][Cin][4][4], n = ci, c = co
+        break;
+      }
+      case TFC_OP_CONVT: {
+        // dx[i] = sum_k dy[2i-1+k] W[k]: parity plane 0 holds k in {1,3} at plane rows {i, i+1}; plane 1 holds k in {0,2} at {i-1, i}
+        d.SS = 2; d.nplanes = 4;
+        static const int kOf[2][2] = {{1, 3}, {0, 2}};
+        for (int ppy = 0; ppy < 2; ++ppy)
+          for (int ppx = 0; ppx < 2; ++ppx) {
+            TfcPlane& p = d.plane[ppy * 2 + ppx];
+            p.py = ppy; p.px = ppx; p.dy0 = ppy ? -1 : 0; p.dx0 = ppx ? -1 : 0; p.hh = 9; p.hw = 17; p.ntaps = 4;
+            for (int jy = 0; jy < 2; ++jy)
+              for (int jx = 0; jx < 2; ++jx) {
+                const int t = jy * 2 + jx;
+                p.tap_dy[t] = jy; p.tap_dx[t] = jx; p.tap_slot[t] = kOf[ppy][jy] * 4 + kOf[ppx][jx];
+              }
+          }
+        if (wm) *wm = {Cin, Cout, (long long)Cout * 16, 16};   // W[ci][co][k]: n = ci, c = co
+        break;
+      }
+      case TFC_OP_UPCONV: {
+        // du[a] = sum over parity planes p of dy, taps k with a' = a - off(p,k):  plane row a' = a + (-off)
+        d.SS = 2; d.nplanes = 4;
+        for (int ppy = 0; ppy < 2; ++ppy)
+          for (int ppx = 0; ppx < 2; ++ppx) {
+            TfcPlane& p = d.plane[ppy * 2 + ppx];
+            p.py = ppy; p.px = ppx; p.dy0 = ppy ? -1 : 0; p.dx0 = ppx ? -1 : 0; p.hh = 10; p.hw = 18; p.ntaps = 16;
+            for (int ky = 0; ky < 4; ++ky)
+              for (int kx = 0; kx < 4; ++kx) {
+                const int t = ky * 4 + kx;
+                p.tap_dy[t] = -kUpOff[ppy][ky] - p.dy0; p.tap_dx[t] = -kUpOff[ppx][kx] - p.dx0; p.tap_slot[t] = t;
+              }
+          }
+        if (wm) *wm = {Cin, Cout, 16, (long long)Cin * 16};    // Conv2d weight [Cout][Cin][4][4]: n = ci, c = co
+        break;
+      }
+      default: return fail(-1, "unknown op %d", op);
+    }
+  }
+  set_tiles(d);
+  // sanity: every tap must stay inside the staged halo
+  for (int pl = 0; pl < d.nplanes; ++pl) {
+    const TfcPlane& p = d.plane[pl];
+    if (p.hh > TFC_MAX_HH || p.hw > TFC_MAX_HW) return fail(-1, "halo too large");
+    for (int t = 0; t < p.ntaps; ++t)
+      if (p.tap_dy[t] < 0 || p.tap_dx[t] < 0 || p.tap_dy[t] + TFC_TILE_H > p.hh || p.tap_dx[t] + TFC_TILE_W > p.hw)
+        return fail(-1, "tap %d of plane %d leaves the halo (op %d pass %d)", t, pl, op, pass);
+  }
+  return 0;
+}
+
+static int check_common(int dt, int op, int N, int H, int W, int Cin, int Cout) {
+  REQUIRE(dt == TFC_DT_BF16 || dt == TFC_DT_F32, "bad dtype %d", dt);
+  REQUIRE(op >= 0 && op <= 3, "bad op %d", op);
+  REQUIRE(N > 0 && H > 1 && W > 1 && Cin > 0 && Cout > 0, "bad dims N=%d H=%d W=%d Cin=%d Cout=%d", N, H, W, Cin, Cout);
+  REQUIRE((long long)N * (2 * H) * (2 * W) * (long long)(pad8(Cin) > pad8(Cout) ? pad8(Cin) : pad8(Cout)) < 2147483647LL,
+          "tensor exceeds 2^31 elements");
+  const int es = es_of(dt);
+  REQUIRE(pad8(Cin) * es <= 64 || (pad8(Cin) * es) % 64 == 0, "Cin=%d: padded channel bytes must be <= 64 or a multiple of 64", Cin);
+  REQUIRE(pad8(Cout) * es <= 64 || (pad8(Cout) * es) % 64 == 0, "Cout=%d: padded channel bytes must be <= 64 or a multiple of 64", Cout);
+  return 0;
+}
+static int check_pitch(int dt, int pitch, int cpad, const char* what) {
+  const int ue = 16 / es_of(dt);
+  REQUIRE(pitch >= cpad && pitch % ue == 0, "%s pitch %d must be >= %d and a multiple of %d", what, pitch, cpad, ue);
+  return 0;
+}
+static int check_ptr16(const void* p, const char* what) {
+  REQUIRE(p != nullptr && (((uintptr_t)p) & 15) == 0, "%s must be a 16-byte aligned device pointer", what);
+  return 0;
+}
+
+static size_t phase_packed_bytes(int dt, int op, int pass, int Cin, int Cout) {
+  TfcGather d;
+  if (build_desc(op, pass, 0, 1, 16, 16, Cin, Cout, pad8(Cin), pad8(Cout), &d, nullptr)) return 0;
+  return tfc_packed_bytes(d, es_of(dt));
+}
+
+extern "C" size_t tfc_conv_packed_bytes(int dt, int op, int pass, int Cin, int Cout) {
+  if (pass < 0 || pass > 1 || op < 0 || op > 3) return 0;
+  return phase_packed_bytes(dt, op, pass, Cin, Cout) * num_phases(op, pass);
+}
+
+extern "C" int tfc_conv_pack(void* stream, int dt, int op, int pass, const float* w, const float* scale, void* packed, int Cin, int Cout) {
+  if (int e = check_common(dt, op, 1, 16, 16, Cin, Cout)) return e;
+  REQUIRE(pass == 0 || pass == 1, "pass must be 0 (fwd) or 1 (dgrad)");
+  if (int e = check_ptr16(packed, "packed")) return e;
+  REQUIRE(w != nullptr, "w is null");
+  const size_t pb = phase_packed_bytes(dt, op, pass, Cin, Cout);
+  for (int ph = 0; ph < num_phases(op, pass); ++ph) {
+    TfcGather d;
+    WeightMap wm;
+    if (int e = build_desc(op, pass, ph, 1, 16, 16, Cin, Cout, pad8(Cin), pad8(Cout), &d, &wm)) return e;
+    CHECK_HIP(tfc_launch_pack(dt, d, w, scale, (char*)packed + ph * pb, wm.Nreal, wm.Creal, wm.sn, wm.sc, (hipStream_t)stream), "tfc_conv_pack");
+  }
+  return 0;
+}
+
+static double conv_flop(int op, int N, int H, int W, int Cin, int Cout) {
+  const double oh = out_hw(op, H), ow = out_hw(op, W);
+  const double taps = (op == TFC_OP_CONVT) ? 4.0 : 16.0;
+  return 2.0 * N * oh * ow * (double)Cin * Cout * taps;
+}
+
+extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
+                            const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, int flags) {
+  if (int e = check_common(dt, op, N, H, W, Cin, Cout)) return e;
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(packed, "packed")) return e;
+  if (int e = check_pitch(dt, x_pitch, pad8(Cin), "x")) return e;
+  if (flags & TFC_EP_TANH_NCHW) { REQUIRE(out_nchw != nullptr, "out_nchw is null"); }
+  else { REQUIRE(y != nullptr, "y is null"); REQUIRE(y_pitch >= Cout, "y pitch %d < Cout %d", y_pitch, Cout); }
+  if (flags & TFC_EP_BIAS) REQUIRE(bias != nullptr, "bias is null");
+  if (flags & TFC_EP_STATS) REQUIRE(stats != nullptr, "stats is null");
+  const size_t pb = phase_packed_bytes(dt, op, 0, Cin, Cout);
+  const int nph = num_phases(op, 0);
+  ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
+  for (int ph = 0; ph < nph; ++ph) {
+    TfcGather d;
+    if (int e = build_desc(op, 0, ph, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, nullptr)) return e;
+    CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + ph * pb, y, bias, stats, out_nchw, flags, (hipStream_t)stream), "tfc_conv_fwd");
+  }
+  return 0;
+}
+
+extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
+                              const void* packed, void* dx, int dx_pitch, int flags) {
+  if (int e = check_common(dt, op, N, H, W, Cin, Cout)) return e;
+  if (int e = check_ptr16(dy, "dy")) return e;
+  if (int e = check_ptr16(packed, "packed")) return e;
+  if (int e = check_pitch(dt, dy_pitch, pad8(Cout), "dy")) return e;
+  REQUIRE(dx != nullptr && dx_pitch >= Cin, "dx null or pitch %d < Cin %d", dx_pitch, Cin);
+  REQUIRE((flags & ~TFC_EP_ACCUM) == 0, "dgrad supports only TFC_EP_ACCUM");
+  TfcGather d;
+  if (int e = build_desc(op, 1, 0, N, H, W, Cin, Cout, dy_pitch, dx_pitch, &d, nullptr)) return e;
+  ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
+  CHECK_HIP(tfc_launch_igemm(dt, d, dy, packed, dx, nullptr, nullptr, nullptr, flags, (hipStream_t)stream), "tfc_conv_dgrad");
+  return 0;
+}
+
+extern "C" size_t tfc_conv_wgrad_ws_bytes(int op, int Cin, int Cout) { (void)op; return (size_t)16 * Cin * Cout * sizeof(float); }
+
+extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, const void* dy, int dy_pitch, int N, int H, int W,
+                              int Cin, int Cout, void* ws, float* dw, int accumulate) {
+  if (int e = check_common(dt, op, N, H, W, Cin, Cout)) return e;
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(dy, "dy")) return e;
+  if (int e = check_pitch(dt, x_pitch, pad8(Cin), "x")) return e;
+  if (int e = check_pitch(dt, dy_pitch, pad8(Cout), "dy")) return e;
+  REQUIRE(ws != nullptr && dw != nullptr, "ws / dw null");
+  hipStream_t st = (hipStream_t)stream;
+  CHECK_HIP(hipMemsetAsync(ws, 0, tfc_conv_wgrad_ws_bytes(op, Cin, Cout), st), "tfc_conv_wgrad memset");
+  WeightMap wm{};
+  {
+    ProfScope prof(1, conv_flop(op, N, H, W, Cin, Cout), st);
+    for (int ph = 0; ph < num_phases(op, 2); ++ph) {
+      TfcGather d;
+      if (int e = build_desc(op, 2, ph, N, H, W, Cin, Cout, x_pitch, dy_pitch, &d, &wm)) return e;
+      CHECK_HIP(tfc_launch_wgrad(dt, d, dy, x, (float*)ws, pad8(Cout), Cout, Cin, st), "tfc_conv_wgrad");
+    }
+  }
+  CHECK_HIP(tfc_launch_wgrad_finish((const float*)ws, dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
+  return 0;
+}
+
+// ---- fused activation family ------------------------------------------------------------------------------------
+static int fill_act(ActParams& p, int dt, int N, int H, int W, int C, int x_pitch, int o_pitch, int norm, float slope, int pool,
+                    float drop_p, uint32_t seed) {
+  REQUIRE(dt == TFC_DT_BF16 || dt == TFC_DT_F32, "bad dtype");
+  const int ue = 16 / es_of(dt);
+  REQUIRE(C % ue == 0, "C=%d must be a multiple of %d", C, ue);
+  const int cv = C / ue;
+  REQUIRE(cv <= 256 && (256 % cv) == 0, "C/%d = %d must divide 256", ue, cv);
+  REQUIRE(pool >= 0 && pool <= 2, "bad pool %d", pool);
+  REQUIRE(pool == 0 || (H >= 3 && W >= 3), "reflect pad needs H,W >= 3");
+  REQUIRE(x_pitch % ue == 0 && o_pitch % ue == 0, "pitches must be multiples of %d", ue);
+  REQUIRE(drop_p >= 0.f && drop_p < 1.f, "drop_p out of range");
+  p.N = N; p.H = H; p.W = W; p.C = C;
+  p.Ho = pool == 2 ? (H - 1) / 2 + 1 : H;
+  p.Wo = pool == 2 ? (W - 1) / 2 + 1 : W;
+  p.x_pitch = x_pitch; p.o_pitch = o_pitch; p.pool = pool; p.norm = norm; p.slope = slope; p.eps = 1e-5f;
+  p.drop_thresh24 = (unsigned)lrintf(drop_p * 16777216.f);
+  p.seed = seed;
+  p.drop_scale = 1.f / (1.f - drop_p);
+  return 0;
+}
+
+extern "C" int tfc_act_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* stats, int norm,
+                           float slope, int pool, float drop_p, uint32_t seed, void* y, int y_pitch, float* stats_out) {
+  ActParams p;
+  if (int e = fill_act(p, dt, N, H, W, C, x_pitch, y_pitch, norm, slope, pool, drop_p, seed)) return e;
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(y, "y")) return e;
+  REQUIRE(!norm || stats, "stats is null");
+  CHECK_HIP(tfc_launch_act_fwd(dt, p, x, stats, y, stats_out, (hipStream_t)stream), "tfc_act_fwd");
+  return 0;
+}
+
+extern "C" int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int dy_pitch, const void* x, int x_pitch, int N, int H, int W, int C,
+                           const float* stats, int norm, float slope, int pool, float drop_p, uint32_t seed, float* rstats, void* dx, int dx_pitch) {
+  ActParams p;
+  if (int e = fill_act(p, dt, N, H, W, C, x ? x_pitch : C, dy_pitch, norm, slope, pool, drop_p, seed)) return e;
+  REQUIRE(mode >= 0 && mode <= 2, "bad mode");
+  if (int e = check_ptr16(dy, "dy")) return e;
+  REQUIRE(!norm || (stats && x), "norm needs stats and x");
+  REQUIRE(mode == 0 || (norm && rstats), "modes 1/2 need norm and rstats");
+  REQUIRE(mode == 1 || dx, "dx is null");
+  const void* xx = x ? x : dy;
+  CHECK_HIP(tfc_launch_act_bwd(dt, mode, p, dy, xx, stats, rstats, dx ? dx : (void*)dy, x ? 1 : 0, dx_pitch, (hipStream_t)stream), "tfc_act_bwd");
+  return 0;
+}
+
+extern "C" int tfc_dropout_mask(void* stream, uint8_t* keep, long long n, float drop_p, uint32_t seed) {
+  REQUIRE(keep && n > 0, "bad args");
+  CHECK_HIP(tfc_launch_dropout_mask(keep, n, seed, (unsigned)lrintf(drop_p * 16777216.f), (hipStream_t)stream), "tfc_dropout_mask");
+  return 0;
+}
+
+extern "C" int tfc_pack_nhwc8(void* stream, int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int H, int W) {
+  REQUIRE(a && out && Ca > 0 && Ca + Cb <= 8 && (Cb == 0 || b), "bad args");
+  CHECK_HIP(tfc_launch_pack_nhwc8(dt, a, Ca, b, Cb, out, N, H * W, (hipStream_t)stream), "tfc_pack_nhwc8");
+  return 0;
+}
+extern "C" int tfc_unpack_nchw(void* stream, int dt, const void* in, int pitch, int c0, int C, float* out, int N, int H, int W, float alpha, float beta) {
+  REQUIRE(in && out && C > 0 && c0 >= 0 && c0 + C <= pitch, "bad args");
+  CHECK_HIP(tfc_launch_unpack_nchw(dt, in, pitch, c0, C, out, N, H * W, alpha, beta, (hipStream_t)stream), "tfc_unpack_nchw");
+  return 0;
+}
+extern "C" int tfc_tanh_bwd_pack(void* stream, int dt, const float* g, const float* y, void* dyraw, float* dbias, int N, int C, int H, int W) {
+  REQUIRE(g && y && dyraw && C > 0 && C <= 4, "bad args (C <= 4)");
+  CHECK_HIP(tfc_launch_tanh_bwd_pack(dt, g, y, dyraw, dbias, N, C, H * W, (hipStream_t)stream), "tfc_tanh_bwd_pack");
+  return 0;
+}
+extern "C" int tfc_colsum(void* stream, int dt, const void* x, long long rows, int pitch, int C, float* out) {
+  const int ue = 16 / es_of(dt);
+  REQUIRE(x && out && rows > 0 && C % ue == 0 && (256 % (C / ue)) == 0 && C / ue <= 256, "bad args");
+  CHECK_HIP(tfc_launch_colsum(dt, x, rows, pitch, C, out, (hipStream_t)stream), "tfc_colsum");
+  return 0;
+}
+extern "C" int tfc_cast(void* stream, int dt, int to_f32, const void* x, void* y, long long n) {
+  REQUIRE(x && y && n > 0, "bad args");
+  CHECK_HIP(tfc_launch_cast(dt, to_f32, x, y, n, (hipStream_t)stream), "tfc_cast");
+  return 0;
+}
+extern "C" int tfc_axpby(void* stream, float* out, const float* x, const float* y, long long n, float a, float b) {
+  REQUIRE(out && x && n > 0, "bad args");
+  CHECK_HIP(tfc_launch_axpby(out, x, y, n, a, b, (hipStream_t)stream), "tfc_axpby");
+  return 0;
+}
+
+extern "C" int tfc_spectral_norm_step(void* stream, const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter) {
+  REQUIRE(W && u && v && sigma2 && ws && R > 0 && K > 0, "bad args");
+  CHECK_HIP(tfc_launch_sn_step(W, u, v, sigma2, ws, R, K, power_iter, 1e-12f, (hipStream_t)stream), "tfc_spectral_norm_step");
+  return 0;
+}
+extern "C" int tfc_spectral_norm_bwd(void* stream, const float* G, const float* W, const float* u, const float* v, const float* sigma2,
+                                     float* ws, float* gout, int R, int K, int accumulate) {
+  REQUIRE(G && W && u && v && sigma2 && ws && gout, "bad args");
+  CHECK_HIP(tfc_launch_sn_bwd(G, W, u, v, sigma2, ws, gout, R, K, accumulate, (hipStream_t)stream), "tfc_spectral_norm_bwd");
+  return 0;
+}
+
+extern "C" int tfc_patch16_triplet(void* stream, const float* fake, const float* real, const int* neg_idx_host, int N, int C,
+                                   float* loss, float* dfake, float gscale) {
+  REQUIRE(fake && real && neg_idx_host && loss && N > 0 && C > 0, "bad args");
+  for (int i = 0; i < 16; ++i) REQUIRE(neg_idx_host[i] >= 0 && neg_idx_host[i] < 16, "neg_idx[%d]=%d out of range", i, neg_idx_host[i]);
+  CHECK_HIP(tfc_launch_triplet16(fake, real, neg_idx_host, N, C, 1.0f, 1e-6f, loss, dfake, gscale, (hipStream_t)stream), "tfc_patch16_triplet");
+  return 0;
+}
+extern "C" int tfc_fft_spectrum(void* stream, const float* img, long long batch_stride, long long chan_stride, int row_stride, int C, int S,
+                                int wins_x, int wins_y, int N, float* amp, float* pha, int shift) {
+  REQUIRE(img && amp && pha && (S == 64 || S == 256) && (C == 1 || C == 3) && wins_x > 0 && wins_y > 0 && N > 0, "bad args");
+  CHECK_HIP(tfc_launch_spectrum(img, batch_stride, chan_stride, row_stride, C, S, wins_x, wins_x * wins_y, N * wins_x * wins_y, amp, pha, shift, (hipStream_t)stream), "tfc_fft_spectrum");
+  return 0;
+}
+extern "C" int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first) {
+  REQUIRE(a && b && out && n > 0, "bad args");
+  if (zero_first) CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream), "tfc_l1_sum memset");
+  CHECK_HIP(tfc_launch_l1_sum(a, b, n, scale, out, (hipStream_t)stream), "tfc_l1_sum");
+  return 0;
+}
+extern "C" int tfc_bce_relativistic(void* stream, int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode,
+                                    float* loss, void* da, void* db, float gscale) {
+  REQUIRE(a && b && loss && n > 0 && stride > 0 && (mode == 0 || mode == 1), "bad args");
+  CHECK_HIP(tfc_launch_bce_rel(dt, a, b, n, stride, t1, t2, mode, loss, da, db, gscale, (hipStream_t)stream), "tfc_bce_relativistic");
+  return 0;
+}
+extern "C" int tfc_adam_step(void* stream, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                             int step, float gscale) {
+  REQUIRE(p && g && m && v && n > 0 && step >= 1, "bad args");
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2 = 1.f - powf(b2, (float)step);
+  CHECK_HIP(tfc_launch_adam(p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, (hipStream_t)stream), "tfc_adam_step");
+  return 0;
+}
+extern "C" int tfc_probe_mfma(void* stream, float* out) {
+  REQUIRE(out, "out is null");
+  CHECK_HIP(tfc_launch_probe(out, (hipStream_t)stream), "tfc_probe_mfma");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host emulator of the gather model (CPU tests only): consumes the SAME descriptors and the SAME packed operand
+// stream layout as the kernels (fp32 units), so descriptor / packing / phase bugs show up without a GPU.
+//   pass 0: x [N][H][W][pad8(Cin)]    -> y [N][OH][OW][pad8(Cout)]
+//   pass 1: x = dy [N][OH][OW][pad8(Cout)] -> y = dx [N][H][W][pad8(Cin)]
+//   pass 2: x [N][H][W][pad8(Cin)], w_host = dy [N][OH][OW][pad8(Cout)] -> y = dw (torch layout)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int tfc_host_emulate_conv(int op, int pass, int es, const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout) {
+  REQUIRE(pass >= 0 && pass <= 2 && op >= 0 && op <= 3 && (es == 2 || es == 4), "bad op/pass/es");
+  const int UE = 16 / es;                                        // elements per 16-byte unit in the emulated geometry
+  const int OH = out_hw(op, H), OW = out_hw(op, W);
+  const int inC = pass == 1 ? pad8(Cout) : pad8(Cin);
+  const int outC = pass == 1 ? pad8(Cin) : pad8(Cout);
+  if (pass == 2) {
+    std::vector<double> acc((size_t)16 * Cout * Cin, 0.0);
+    WeightMap wm{};
+    for (int ph = 0; ph < num_phases(op, 2); ++ph) {
+      TfcGather d;
+      if (int e = build_desc(op, 2, ph, N, H, W, Cin, Cout, inC, outC, &d, &wm)) return e;
+      const TfcPlane& p = d.plane[0];
+      for (int img = 0; img < N; ++img)
+        for (int a = 0; a < d.GH; ++a)
+          for (int b = 0; b < d.GW; ++b) {
+            const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+            const float* dyp = w + ((size_t)(img * d.OH + oy) * d.OW + ox) * outC;
+            const int ta = a % TFC_TILE_H, tb = b % TFC_TILE_W, a0 = a - ta, b0 = b - tb;
+            for (int t = 0; t < p.ntaps; ++t) {
+              const int sy = (a0 + p.dy0 + ta + p.tap_dy[t]) * d.SS + p.py, sx = (b0 + p.dx0 + tb + p.tap_dx[t]) * d.SS + p.px;
+              if (sy < 0 || sy >= d.IH || sx < 0 || sx >= d.IW) continue;
+              const float* xp = x + ((size_t)(img * d.IH + sy) * d.IW + sx) * inC;
+              for (int n = 0; n < Cout; ++n)
+                for (int c = 0; c < Cin; ++c) acc[((size_t)p.tap_slot[t] * Cout + n) * Cin + c] += (double)dyp[n] * xp[c];
+            }
+          }
+    }
+    for (int n = 0; n < Cout; ++n)
+      for (int c = 0; c < Cin; ++c)
+        for (int s = 0; s < 16; ++s) y[(long long)n * wm.sn + (long long)c * wm.sc + s] = (float)acc[((size_t)s * Cout + n) * Cin + c];
+    return 0;
+  }
+  for (int ph = 0; ph < num_phases(op, pass); ++ph) {
+    TfcGather d;
+    WeightMap wm;
+    if (int e = build_desc(op, pass, ph, N, H, W, Cin, Cout, inC, outC, &d, &wm)) return e;
+    // pack on the host with the kernel's index math
+    const int NB32 = tfc_nb32_padded(d.Nout);
+    const int total_sub = tfc_total_substeps(d, es);
+    const int total_units = total_sub * NB32 * 64;
+    std::vector<float> wp((size_t)total_units * UE);
+    for (int idx = 0; idx < total_units; ++idx) {
+      int n, slot, c0;
+      tfc_pack_locate(d, es, NB32, idx, &n, &slot, &c0);
+      for (int e = 0; e < UE; ++e) {
+        const int c = c0 + e;
+        wp[(size_t)idx * UE + e] = (n < wm.Nreal && c < wm.Creal && slot >= 0) ? w[(long long)n * wm.sn + (long long)c * wm.sc + slot] : 0.f;
+      }
+    }
+    const int PB = tfc_pb(d.Cin_pad, es), UPP = PB >> 4, CK = PB / es;
+    const int nchunks = d.Cin_pad * es / PB;
+    for (int img = 0; img < N; ++img)
+      for (int tyb = 0; tyb < d.tiles_y; ++tyb)
+        for (int txb = 0; txb < d.tiles_x; ++txb) {
+          const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+          for (int ty = 0; ty < TFC_TILE_H; ++ty)
+            for (int tx = 0; tx < TFC_TILE_W; ++tx) {
+              const int a = a0 + ty, b = b0 + tx;
+              if (a >= d.GH || b >= d.GW) continue;
+              const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+              for (int n = 0; n < d.Nout; ++n) {
+                const int nb = n >> 5, rn = n & 31;
+                double acc = 0.0;
+                int gs = 0;
+                for (int cc = 0; cc < nchunks; ++cc)
+                  for (int pl = 0; pl < d.nplanes; ++pl) {
+                    const TfcPlane& p = d.plane[pl];
+                    const int nsub = tfc_nsub(p.ntaps, PB);
+                    for (int s = 0; s < nsub; ++s, ++gs)
+                      for (int h = 0; h < 2; ++h) {
+                        const int u = 2 * s + h, tap = u / UPP, g = u % UPP;
+                        const int sy = (a0 + p.dy0 + ty + p.tap_dy[tap]) * d.SS + p.py;
+                        const int sx = (b0 + p.dx0 + tx + p.tap_dx[tap]) * d.SS + p.px;
+                        if (sy < 0 || sy >= d.IH || sx < 0 || sx >= d.IW) continue;
+                        const float* xp = x + ((size_t)(img * d.IH + sy) * d.IW + sx) * inC + cc * CK + g * UE;
+                        const float* wq = &wp[((size_t)(gs * NB32 + nb) * 64 + (h * 32 + rn)) * UE];
+                        for (int e = 0; e < UE; ++e) acc += (double)xp[e] * wq[e];
+                      }
+                  }
+                y[((size_t)(img * d.OH + oy) * d.OW + ox) * outC + n] = (float)acc;
+              }
+            }
+        }
+  }
+  return 0;
+}

@@ -1,0 +1,81 @@
+// Device-side helpers shared by all TFC-GAN HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tfc_desc.h"
+
+typedef unsigned short bf16_t;                                   // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;      // one MFMA 32x32x16 operand fragment
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;                                           // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int UE = 8;                                    // elements per 16-byte unit
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+template <> struct ElemTraits<float> {
+  static constexpr int UE = 4;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+
+// 16-byte vector <-> UE floats
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& u, float* v);
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* v) {
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& u, float* v) {
+  v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* v);
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* v) {
+  uint4 u;
+  u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+  u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  return u;
+}
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* v) {
+  uint4 u; u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
+  return u;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// counter-based dropout RNG: keep-mask bit for element `idx` of stream `seed` (murmur3 finaliser of a 64-bit key)
+__host__ __device__ __forceinline__ uint32_t tfc_hash32(uint32_t seed, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  x += seed * 0x27D4EB2Fu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+  return x;
+}
+// p_keep threshold compare on the top 24 bits
+__host__ __device__ __forceinline__ bool tfc_keep(uint32_t seed, uint32_t idx, uint32_t thresh24) {
+  return (tfc_hash32(seed, idx) >> 8) >= thresh24;                // drop with probability thresh24 / 2^24
+}
+
+// XCD-aware bijective block remap: blocks b and b+8 share an XCD (observed round-robin dispatch), so give each
+// XCD a contiguous range of logical ids; neighbouring tiles then hit the same 4 MiB L2. Speed only, never correctness.
+__device__ __forceinline__ int tfc_xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, w = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
+}

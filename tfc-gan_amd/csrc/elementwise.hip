@@ -1,0 +1,628 @@
+// HBM-bound fused kernels of the TFC-GAN hot path (gfx950): everything between the convolutions.
+// All activation tensors are NHWC with an explicit pixel pitch; each lane moves 16 bytes (8 bf16 / 4 fp32).
+//
+//   act_fwd   : [InstanceNorm] -> LeakyReLU/ReLU/identity -> [BlurPool stride 2 | blur stride 1] -> [Dropout]
+//               (+ optional InstanceNorm statistics of the result)   reference: UNetDown / UNetUp bodies,
+//               TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py:102-134, Discriminator1 blocks :187-200
+//   act_bwd   : the exact transpose, in reduce / apply phases for the InstanceNorm backward
+//   pack/unpack NCHW fp32 <-> NHWC8, tanh backward, column sums (bias grads), spectral-norm power iteration,
+//   relativistic BCE-with-logits, Adam, axpby, dropout-mask export.
+#include "common.h"
+
+// BlurPool taps: [1,3,3,1]/8 per dimension (antialiased_cnns.BlurPool, filt_size 4), reflect pad (1,2).
+__device__ __forceinline__ float blur_w(int k) { return (k == 0 || k == 3) ? 0.125f : 0.375f; }
+__device__ __forceinline__ int reflect_idx(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
+
+// For input coordinate y (0..n-1) of a reflect-padded blur with `stride`, list the (output index, weight) pairs that
+// read it: padded coordinate aliases p of y are y itself, -1 (if y==1), n (if y==n-2), n+1 (if y==n-3).
+__device__ __forceinline__ int blur_transpose_taps(int y, int n, int no, int stride, int* oidx, float* w) {
+  int cnt = 0;
+  int alias[4];
+  int na = 0;
+  alias[na++] = y;
+  if (y == 1) alias[na++] = -1;
+  if (y == n - 2) alias[na++] = n;
+  if (y == n - 3) alias[na++] = n + 1;
+  for (int ai = 0; ai < na; ++ai) {
+    const int p = alias[ai];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = p + 1 - k;                                   // = o*stride
+      if (t < 0) continue;
+      if (stride == 2 && (t & 1)) continue;
+      const int o = stride == 2 ? (t >> 1) : t;
+      if (o < no) { oidx[cnt] = o; w[cnt] = blur_w(k); ++cnt; }
+    }
+  }
+  return cnt;
+}
+
+
+// block = 256 threads = PPB pixels x CV channel vectors; grid = (pixel blocks, N); grid-stride over pixels
+template <typename T, bool STATS_OUT>
+__global__ void __launch_bounds__(256)
+tfc_act_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ out,
+                   float* stats_out) {
+  constexpr int UE = ElemTraits<T>::UE;
+  __shared__ float red[2][256 * 8 / 8 * 8];                      // [2][256*UE] worst case UE=8 -> 2048 floats each
+  const int CV = p.C / UE;
+  const int PPB = 256 / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  const int n = blockIdx.y;
+  const int npix = p.Ho * p.Wo;
+  float mean[UE], rstd[UE];
+  if (p.norm) {
+    const float inv = 1.f / (float)(p.H * p.W);
+#pragma unroll
+    for (int e = 0; e < UE; ++e) {
+      const float s1 = stats[((size_t)n * p.C + cv * UE + e) * 2 + 0];
+      const float s2 = stats[((size_t)n * p.C + cv * UE + e) * 2 + 1];
+      const float m = s1 * inv;
+      const float var = fmaxf(s2 * inv - m * m, 0.f);
+      mean[e] = m;
+      rstd[e] = rsqrtf(var + p.eps);
+    }
+  }
+  float a1[UE], a2[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+
+  const T* xn = x + (size_t)n * p.H * p.W * p.x_pitch;
+  T* on = out + (size_t)n * npix * p.o_pitch;
+  if (pl < PPB) {
+    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+      const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+      float r[UE];
+#pragma unroll
+      for (int e = 0; e < UE; ++e) r[e] = 0.f;
+      if (p.pool == 0) {
+        float v[UE];
+        unpack16<T>(*reinterpret_cast<const uint4*>(xn + (size_t)(oy * p.W + ox) * p.x_pitch + cv * UE), v);
+#pragma unroll
+        for (int e = 0; e < UE; ++e) {
+          float t = p.norm ? (v[e] - mean[e]) * rstd[e] : v[e];
+          r[e] = t > 0.f ? t : t * p.slope;
+        }
+      } else {
+        const int s = p.pool;                                     // 1 or 2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int yy = reflect_idx(oy * s - 1 + i, p.H);
+          const float wy = blur_w(i);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int xx = reflect_idx(ox * s - 1 + j, p.W);
+            const float w = wy * blur_w(j);
+            float v[UE];
+            unpack16<T>(*reinterpret_cast<const uint4*>(xn + (size_t)(yy * p.W + xx) * p.x_pitch + cv * UE), v);
+#pragma unroll
+            for (int e = 0; e < UE; ++e) {
+              float t = p.norm ? (v[e] - mean[e]) * rstd[e] : v[e];
+              t = t > 0.f ? t : t * p.slope;
+              r[e] += w * t;
+            }
+          }
+        }
+      }
+      if (p.drop_thresh24) {
+        const uint32_t base = (uint32_t)(((size_t)n * npix + pix) * p.C + cv * UE);
+#pragma unroll
+        for (int e = 0; e < UE; ++e) r[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? r[e] * p.drop_scale : 0.f;
+      }
+      if (STATS_OUT) {
+#pragma unroll
+        for (int e = 0; e < UE; ++e) { a1[e] += r[e]; a2[e] += r[e] * r[e]; }
+      }
+      *reinterpret_cast<uint4*>(on + (size_t)pix * p.o_pitch + cv * UE) = pack16<T>(r);
+    }
+  }
+  if (STATS_OUT) {
+    // block reduction over the PPB pixel lanes, then one atomic per channel
+#pragma unroll
+    for (int e = 0; e < UE; ++e) { red[0][threadIdx.x * UE + e] = a1[e]; red[1][threadIdx.x * UE + e] = a2[e]; }
+    __syncthreads();
+    const int nch = CV * UE;                                      // == C
+    for (int c = threadIdx.x; c < nch; c += 256) {
+      float s1 = 0.f, s2 = 0.f;
+      const int ccv = c / UE, ce = c % UE;
+      for (int q = 0; q < PPB; ++q) { s1 += red[0][(q * CV + ccv) * UE + ce]; s2 += red[1][(q * CV + ccv) * UE + ce]; }
+      atomicAdd(&stats_out[((size_t)n * p.C + c) * 2 + 0], s1);
+      atomicAdd(&stats_out[((size_t)n * p.C + c) * 2 + 1], s2);
+    }
+  }
+}
+
+// backward. mode 0: dx = g' (no norm)   mode 1: rstats += (sum g', sum g'*xhat)   mode 2: dx = rstd*(g' - mg - xhat*mgx)
+//   g' = [blur^T](dropmask * dout) * act'(xhat);  xhat = norm ? (x-mean)*rstd : x;  use_x == 0 => act' = 1
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256)
+tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats,
+                   float* rstats, T* __restrict__ dx, int use_x, int dx_pitch) {
+  constexpr int UE = ElemTraits<T>::UE;
+  __shared__ float red[2][2048];
+  const int CV = p.C / UE;
+  const int PPB = 256 / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  const int n = blockIdx.y;
+  const int npix = p.H * p.W;
+  const int nopix = p.Ho * p.Wo;
+  float mean[UE], rstd[UE], mg[UE], mgx[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) { mean[e] = 0.f; rstd[e] = 1.f; mg[e] = 0.f; mgx[e] = 0.f; }
+  if (p.norm) {
+    const float inv = 1.f / (float)npix;
+#pragma unroll
+    for (int e = 0; e < UE; ++e) {
+      const size_t si = ((size_t)n * p.C + cv * UE + e) * 2;
+      const float m = stats[si] * inv;
+      const float var = fmaxf(stats[si + 1] * inv - m * m, 0.f);
+      mean[e] = m;
+      rstd[e] = rsqrtf(var + p.eps);
+      if (MODE == 2) { mg[e] = rstats[si] * inv; mgx[e] = rstats[si + 1] * inv; }
+    }
+  }
+  float a1[UE], a2[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  const T* xn = x + (size_t)n * npix * p.x_pitch;
+  const T* dn = dout + (size_t)n * nopix * p.o_pitch;
+  T* dxn = dx + (size_t)n * npix * dx_pitch;
+  if (pl < PPB) {
+    for (int pix = blockIdx.x * PPB + pl; pix < npix; pix += gridDim.x * PPB) {
+      const int y = pix / p.W, xq = pix - y * p.W;
+      float g[UE];
+#pragma unroll
+      for (int e = 0; e < UE; ++e) g[e] = 0.f;
+      if (p.pool == 0) {
+        unpack16<T>(*reinterpret_cast<const uint4*>(dn + (size_t)pix * p.o_pitch + cv * UE), g);
+        if (p.drop_thresh24) {
+          const uint32_t base = (uint32_t)(((size_t)n * nopix + pix) * p.C + cv * UE);
+#pragma unroll
+          for (int e = 0; e < UE; ++e) g[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? g[e] * p.drop_scale : 0.f;
+        }
+      } else {
+        int oy[8], ox[8];
+        float wy[8], wx[8];
+        const int ny = blur_transpose_taps(y, p.H, p.Ho, p.pool, oy, wy);
+        const int nx = blur_transpose_taps(xq, p.W, p.Wo, p.pool, ox, wx);
+        for (int i = 0; i < ny; ++i)
+          for (int j = 0; j < nx; ++j) {
+            const int opix = oy[i] * p.Wo + ox[j];
+            float v[UE];
+            unpack16<T>(*reinterpret_cast<const uint4*>(dn + (size_t)opix * p.o_pitch + cv * UE), v);
+            const float w = wy[i] * wx[j];
+            if (p.drop_thresh24) {
+              const uint32_t base = (uint32_t)(((size_t)n * nopix + opix) * p.C + cv * UE);
+#pragma unroll
+              for (int e = 0; e < UE; ++e) v[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? v[e] * p.drop_scale : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < UE; ++e) g[e] += w * v[e];
+          }
+      }
+      float xh[UE];
+      if (use_x) {
+        float v[UE];
+        unpack16<T>(*reinterpret_cast<const uint4*>(xn + (size_t)pix * p.x_pitch + cv * UE), v);
+#pragma unroll
+        for (int e = 0; e < UE; ++e) {
+          xh[e] = p.norm ? (v[e] - mean[e]) * rstd[e] : v[e];
+          g[e] *= (xh[e] > 0.f ? 1.f : p.slope);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < UE; ++e) xh[e] = 0.f;
+      }
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < UE; ++e) { a1[e] += g[e]; a2[e] += g[e] * xh[e]; }
+      } else {
+        float r[UE];
+#pragma unroll
+        for (int e = 0; e < UE; ++e) r[e] = (MODE == 2) ? rstd[e] * (g[e] - mg[e] - xh[e] * mgx[e]) : g[e];
+        *reinterpret_cast<uint4*>(dxn + (size_t)pix * dx_pitch + cv * UE) = pack16<T>(r);
+      }
+    }
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < UE; ++e) { red[0][threadIdx.x * UE + e] = a1[e]; red[1][threadIdx.x * UE + e] = a2[e]; }
+    __syncthreads();
+    const int nch = CV * UE;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+      float s1 = 0.f, s2 = 0.f;
+      const int ccv = c / UE, ce = c % UE;
+      for (int q = 0; q < PPB; ++q) { s1 += red[0][(q * CV + ccv) * UE + ce]; s2 += red[1][(q * CV + ccv) * UE + ce]; }
+      atomicAdd(&rstats[((size_t)n * p.C + c) * 2 + 0], s1);
+      atomicAdd(&rstats[((size_t)n * p.C + c) * 2 + 1], s2);
+    }
+  }
+}
+
+// column sums: out[c] += sum over rows of x[row][c]   (bias gradients)
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_colsum_kernel(const T* __restrict__ x, long long rows, int pitch, int C, float* out) {
+  constexpr int UE = ElemTraits<T>::UE;
+  __shared__ float red[2048];
+  const int CV = C / UE;
+  const int PPB = 256 / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  float a[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) a[e] = 0.f;
+  if (pl < PPB)
+    for (long long r = (long long)blockIdx.x * PPB + pl; r < rows; r += (long long)gridDim.x * PPB) {
+      float v[UE];
+      unpack16<T>(*reinterpret_cast<const uint4*>(x + r * pitch + cv * UE), v);
+#pragma unroll
+      for (int e = 0; e < UE; ++e) a[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < UE; ++e) red[threadIdx.x * UE + e] = a[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    const int ccv = c / UE, ce = c % UE;
+    for (int q = 0; q < PPB; ++q) s += red[(q * CV + ccv) * UE + ce];
+    atomicAdd(&out[c], s);
+  }
+}
+
+// NCHW fp32 (a: Ca channels, b: Cb channels) -> NHWC with 8 channels (zero padded)
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_pack_nhwc8_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb, T* __restrict__ out,
+                      int N, int HW) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * HW) return;
+  const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float t = 0.f;
+    if (c < Ca) t = a[((size_t)n * Ca + c) * HW + pix];
+    else if (c < Ca + Cb) t = b[((size_t)n * Cb + (c - Ca)) * HW + pix];
+    v[c] = t;
+  }
+  T* o = out + idx * 8;
+  if (sizeof(T) == 2) {
+    *reinterpret_cast<uint4*>(o) = pack16<T>(v);
+  } else {
+    *reinterpret_cast<uint4*>(o) = pack16<T>(v);
+    *reinterpret_cast<uint4*>(o + 4) = pack16<T>(v + 4);
+  }
+}
+
+// NHWC (pitch) channels [c0, c0+C) -> NCHW fp32: out = alpha * in + beta * out
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_unpack_nchw_kernel(const T* __restrict__ in, int pitch, int c0, int C, float* __restrict__ out, int N, int HW,
+                       float alpha, float beta) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * HW) return;
+  const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
+  for (int c = 0; c < C; ++c) {
+    const float v = ElemTraits<T>::ld(in + idx * pitch + c0 + c) * alpha;
+    float* o = out + ((size_t)n * C + c) * HW + pix;
+    *o = beta != 0.f ? v + beta * (*o) : v;
+  }
+}
+
+// generator head backward: dyraw[n,pix,c<3] = g * (1 - y^2)  (NHWC8), bias grad dbias[c] += sum
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_tanh_bwd_pack_kernel(const float* __restrict__ g, const float* __restrict__ y, T* __restrict__ out, float* dbias,
+                         int N, int C, int HW) {
+  __shared__ float red[4][256];
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = 0.f;
+  if (idx < (long long)N * HW) {
+    const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
+    for (int c = 0; c < C; ++c) {
+      const size_t o = ((size_t)n * C + c) * HW + pix;
+      const float yy = y[o];
+      v[c] = g[o] * (1.f - yy * yy);
+    }
+    T* o = out + idx * 8;
+    *reinterpret_cast<uint4*>(o) = pack16<T>(v);
+    if (sizeof(T) == 4) *reinterpret_cast<uint4*>(o + 4) = pack16<T>(v + 4);
+  }
+  if (dbias) {
+    for (int c = 0; c < C && c < 4; ++c) red[c][threadIdx.x] = v[c];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      for (int c = 0; c < C && c < 4; ++c) {
+        float s = red[c][threadIdx.x] + red[c][threadIdx.x + 64] + red[c][threadIdx.x + 128] + red[c][threadIdx.x + 192];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) atomicAdd(&dbias[c], s);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// spectral norm (torch.nn.utils.parametrizations.spectral_norm, 1 power iteration per training forward):
+//   u <- normalize(W v);  v <- normalize(W^T u);  sigma = u . (W v)        W: [R][K] fp32 row-major
+// ---------------------------------------------------------------------------------------------------
+// s[r] = sum_k W[r][k] v[k]   (one wave per row)
+__global__ void __launch_bounds__(256) tfc_sn_mv_kernel(const float* __restrict__ W, const float* __restrict__ v, float* s, int R, int K) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) a += W[(size_t)row * K + k] * v[k];
+  a = wave_sum(a);
+  if (lane == 0) s[row] = a;
+}
+// t[k] = sum_r W[r][k] u[r]   (thread per column, rows split over blockIdx.y, fp32 atomics)
+__global__ void __launch_bounds__(256) tfc_sn_mtv_kernel(const float* __restrict__ W, const float* __restrict__ u, float* t, int R, int K, int rows_per) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = min(R, r0 + rows_per);
+  float a = 0.f;
+  for (int r = r0; r < r1; ++r) a += W[(size_t)r * K + k] * u[r];
+  atomicAdd(&t[k], a);
+}
+// out = x / max(||x||, eps); optionally sigma = dot(out, x2) (x2 may alias x), inv_sigma = 1/sigma. single block.
+__global__ void __launch_bounds__(1024) tfc_sn_normalize_kernel(const float* __restrict__ x, float* out, int n, float eps) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) a += x[i] * x[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  float tot = 0.f;
+  for (int i = 0; i < 16; ++i) tot += red[i];
+  const float inv = 1.f / fmaxf(sqrtf(tot), eps);
+  for (int i = threadIdx.x; i < n; i += 1024) out[i] = x[i] * inv;
+}
+__global__ void __launch_bounds__(1024) tfc_sn_sigma_kernel(const float* __restrict__ u, const float* __restrict__ s, int n, float* sigma2) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) a += u[i] * s[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    sigma2[0] = tot;
+    sigma2[1] = 1.f / tot;
+  }
+}
+// spectral-norm backward: gw = (G - (sum G*Wsn) u v^T) / sigma, Wsn = W/sigma.  pass 1: dot += sum G*W ; pass 2: apply
+__global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += a[i] * b[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) tfc_sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
+                                                                const float* __restrict__ sigma2, const float* __restrict__ gw_dot,
+                                                                float* gout, int R, int K, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)R * K) return;
+  const int r = (int)(i / K), k = (int)(i - (long long)r * K);
+  const float inv = sigma2[1];
+  const float dotws = gw_dot[0] * inv;                           // sum G * Wsn = (sum G*W)/sigma
+  const float val = (G[i] - dotws * u[r] * v[k]) * inv;
+  gout[i] = accumulate ? gout[i] + val : val;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// relativistic BCE-with-logits (reference :554, :628-630).  x = a - b
+//   mode 0 (G): loss = mean BCE(x, t1);                da = dL/dx
+//   mode 1 (D): loss = 0.5*[mean BCE(x,t1) + mean BCE(-x,t2)];  da = dL/dx, db = -dL/dx
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bce_logits(float x, float t) { return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_bce_rel_kernel(const T* __restrict__ a, const T* __restrict__ b, int n, int stride, float t1, float t2, int mode, float* loss,
+                   T* da, T* db, float gscale) {
+  __shared__ float red[4];
+  float l = 0.f;
+  const float invn = 1.f / (float)n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float x = ElemTraits<T>::ld(a + (size_t)i * stride) - ElemTraits<T>::ld(b + (size_t)i * stride);
+    float gx;
+    if (mode == 0) {
+      l += bce_logits(x, t1);
+      gx = (sigmoidf_(x) - t1) * invn;
+    } else {
+      l += 0.5f * (bce_logits(x, t1) + bce_logits(-x, t2));
+      gx = 0.5f * ((sigmoidf_(x) - t1) - (sigmoidf_(-x) - t2)) * invn;
+    }
+    if (da) ElemTraits<T>::st(da + (size_t)i * stride, gx * gscale);
+    if (db) ElemTraits<T>::st(db + (size_t)i * stride, -gx * gscale);
+  }
+  l = wave_sum(l);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * invn);
+}
+
+// Adam (torch.optim.Adam defaults: no weight decay, no amsgrad; reference :461-462)
+__global__ void __launch_bounds__(256)
+tfc_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+tfc_axpby_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y, long long n, float a, float b) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+__global__ void __launch_bounds__(256)
+tfc_dropout_mask_kernel(unsigned char* __restrict__ out, long long n, unsigned seed, unsigned thresh24) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = tfc_keep(seed, (uint32_t)i, thresh24) ? 1 : 0;
+}
+
+// fp32 <-> compute dtype casts of flat buffers (test plumbing and fft inputs)
+template <typename T>
+__global__ void __launch_bounds__(256) tfc_cast_from_f32_kernel(const float* __restrict__ x, T* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) ElemTraits<T>::st(y + i, x[i]);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) tfc_cast_to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = ElemTraits<T>::ld(x + i);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+static inline dim3 act_grid(int npix, int C, int ue, int N) {
+  const int cv = C / ue;
+  const int ppb = 256 / cv;
+  int nb = (npix + ppb - 1) / ppb;
+  int cap = 8192 / (N > 0 ? N : 1);
+  if (cap < 1) cap = 1;
+  if (nb > cap) nb = cap;
+  return dim3(nb, N);
+}
+
+template <typename T>
+static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st) {
+  const dim3 grid = act_grid(p.Ho * p.Wo, p.C, ElemTraits<T>::UE, p.N);
+  if (stats_out)
+    hipLaunchKernelGGL((tfc_act_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)x, stats, (T*)out, stats_out);
+  else
+    hipLaunchKernelGGL((tfc_act_fwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)x, stats, (T*)out, stats_out);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? act_fwd_t<bf16_t>(p, x, stats, out, stats_out, st) : act_fwd_t<float>(p, x, stats, out, stats_out, st);
+}
+template <typename T>
+static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats,
+                            void* dx, int use_x, int dx_pitch, hipStream_t st) {
+  const dim3 grid = act_grid(p.H * p.W, p.C, ElemTraits<T>::UE, p.N);
+  if (mode == 0)
+    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, 0>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
+  else if (mode == 1)
+    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, 1>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
+  else
+    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, 2>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats,
+                              float* rstats, void* dx, int use_x, int dx_pitch, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? act_bwd_t<bf16_t>(mode, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st)
+                           : act_bwd_t<float>(mode, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
+}
+hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, hipStream_t st) {
+  const int ue = dt == TFC_DT_BF16 ? 8 : 4;
+  const int ppb = 256 / (C / ue);
+  long long nb = (rows + ppb - 1) / ppb;
+  if (nb > 2048) nb = 2048;
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_colsum_kernel<bf16_t>), dim3((int)nb), dim3(256), 0, st, (const bf16_t*)x, rows, pitch, C, out);
+  else hipLaunchKernelGGL((tfc_colsum_kernel<float>), dim3((int)nb), dim3(256), 0, st, (const float*)x, rows, pitch, C, out);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_pack_nhwc8(int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int HW, hipStream_t st) {
+  const long long tot = (long long)N * HW;
+  const dim3 grid((unsigned)((tot + 255) / 256));
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_pack_nhwc8_kernel<bf16_t>), grid, dim3(256), 0, st, a, Ca, b, Cb, (bf16_t*)out, N, HW);
+  else hipLaunchKernelGGL((tfc_pack_nhwc8_kernel<float>), grid, dim3(256), 0, st, a, Ca, b, Cb, (float*)out, N, HW);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_unpack_nchw(int dt, const void* in, int pitch, int c0, int C, float* out, int N, int HW, float alpha, float beta, hipStream_t st) {
+  const long long tot = (long long)N * HW;
+  const dim3 grid((unsigned)((tot + 255) / 256));
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_unpack_nchw_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, pitch, c0, C, out, N, HW, alpha, beta);
+  else hipLaunchKernelGGL((tfc_unpack_nchw_kernel<float>), grid, dim3(256), 0, st, (const float*)in, pitch, c0, C, out, N, HW, alpha, beta);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_tanh_bwd_pack(int dt, const float* g, const float* y, void* out, float* dbias, int N, int C, int HW, hipStream_t st) {
+  const long long tot = (long long)N * HW;
+  const dim3 grid((unsigned)((tot + 255) / 256));
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<bf16_t>), grid, dim3(256), 0, st, g, y, (bf16_t*)out, dbias, N, C, HW);
+  else hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<float>), grid, dim3(256), 0, st, g, y, (float*)out, dbias, N, C, HW);
+  return hipGetLastError();
+}
+// one power iteration; ws: float[R + K] scratch (s | t). u:[R] v:[K] updated in place; sigma2: {sigma, 1/sigma}
+hipError_t tfc_launch_sn_step(const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter, float eps, hipStream_t st) {
+  float* s = ws;
+  float* t = ws + R;
+  if (power_iter) {
+    hipLaunchKernelGGL(tfc_sn_mv_kernel, dim3((R + 3) / 4), dim3(256), 0, st, W, v, s, R, K);
+    hipLaunchKernelGGL(tfc_sn_normalize_kernel, dim3(1), dim3(1024), 0, st, s, u, R, eps);
+    hipError_t e = hipMemsetAsync(t, 0, sizeof(float) * K, st);
+    if (e != hipSuccess) return e;
+    const int rows_per = 32;
+    hipLaunchKernelGGL(tfc_sn_mtv_kernel, dim3((K + 255) / 256, (R + rows_per - 1) / rows_per), dim3(256), 0, st, W, u, t, R, K, rows_per);
+    hipLaunchKernelGGL(tfc_sn_normalize_kernel, dim3(1), dim3(1024), 0, st, t, v, K, eps);
+  }
+  hipLaunchKernelGGL(tfc_sn_mv_kernel, dim3((R + 3) / 4), dim3(256), 0, st, W, v, s, R, K);
+  hipLaunchKernelGGL(tfc_sn_sigma_kernel, dim3(1), dim3(1024), 0, st, u, s, R, sigma2);
+  return hipGetLastError();
+}
+// gout = (G - (sum G*W)/sigma * u v^T)/sigma ; dot_ws: 1 float scratch
+hipError_t tfc_launch_sn_bwd(const float* G, const float* W, const float* u, const float* v, const float* sigma2, float* dot_ws,
+                             float* gout, int R, int K, int accumulate, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(dot_ws, 0, sizeof(float), st);
+  if (e != hipSuccess) return e;
+  const long long n = (long long)R * K;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(tfc_dot_kernel, dim3(nb), dim3(256), 0, st, G, W, n, dot_ws);
+  hipLaunchKernelGGL(tfc_sn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, u, v, sigma2, dot_ws, gout, R, K, accumulate);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_bce_rel(int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode, float* loss, void* da, void* db, float gscale, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (e != hipSuccess) return e;
+  int nb = (n + 255) / 256;
+  if (nb > 256) nb = 256;
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_bce_rel_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, n, stride, t1, t2, mode, loss, (bf16_t*)da, (bf16_t*)db, gscale);
+  else hipLaunchKernelGGL((tfc_bce_rel_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)a, (const float*)b, n, stride, t1, t2, mode, loss, (float*)da, (float*)db, gscale);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                           float bc1, float bc2_sqrt, float gscale, hipStream_t st) {
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(tfc_adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_axpby(float* out, const float* x, const float* y, long long n, float a, float b, hipStream_t st) {
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(tfc_axpby_kernel, dim3((int)nb), dim3(256), 0, st, out, x, y, n, a, b);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_dropout_mask(unsigned char* out, long long n, unsigned seed, unsigned thresh24, hipStream_t st) {
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(tfc_dropout_mask_kernel, dim3((int)nb), dim3(256), 0, st, out, n, seed, thresh24);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_cast(int dt, int to_f32, const void* x, void* y, long long n, hipStream_t st) {
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (dt == TFC_DT_BF16) {
+    if (to_f32) hipLaunchKernelGGL((tfc_cast_to_f32_kernel<bf16_t>), dim3((int)nb), dim3(256), 0, st, (const bf16_t*)x, (float*)y, n);
+    else hipLaunchKernelGGL((tfc_cast_from_f32_kernel<bf16_t>), dim3((int)nb), dim3(256), 0, st, (const float*)x, (bf16_t*)y, n);
+  } else {
+    if (to_f32) hipLaunchKernelGGL((tfc_cast_to_f32_kernel<float>), dim3((int)nb), dim3(256), 0, st, (const float*)x, (float*)y, n);
+    else hipLaunchKernelGGL((tfc_cast_from_f32_kernel<float>), dim3((int)nb), dim3(256), 0, st, (const float*)x, (float*)y, n);
+  }
+  return hipGetLastError();
+}

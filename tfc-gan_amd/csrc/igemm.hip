@@ -1,0 +1,566 @@
+// Halo-staged implicit-GEMM convolution kernels for gfx950 (MI355X), bf16 and fp32.
+//
+//   tfc_igemm_kernel   : forward-type gather GEMM (conv fwd, conv dgrad, convT fwd phases, convT dgrad,
+//                        upsample+pad+conv, pad+conv) -- see tfc_desc.h for the abstract model.
+//   tfc_wgrad_kernel   : weight-gradient GEMM (K = pixels) for the same gather descriptors.
+//   tfc_pack_w_kernel  : torch-layout fp32 weights -> MFMA-fragment-ordered operand stream.
+//   tfc_wgrad_finish_kernel : fp32 accumulator [slot][n][c] -> torch-layout gradient.
+//
+// Design (MI355X-first, not a cuDNN-style im2col):
+//   * a workgroup (4 waves) owns an 8x16 tile of output pixels of one image; per 64-byte channel chunk it stages
+//     the (8+3)x(16+3) input halo ONCE in LDS and replays it for all 16 taps, so the K loop over taps is
+//     barrier-free: A fragments are ds_read_b128 from the halo at tap-constant offsets, B fragments are
+//     1-KiB fully coalesced global_load_dwordx4 from a weight stream pre-packed in MFMA fragment order
+//     (L2-resident), software-pipelined in registers;
+//   * LDS image: pixel stride = chunk+16 B, row pitch 24 pixels and rows interleaved over lane parity, which
+//     makes every ds_read_b128 lane group hit 16 distinct 16-byte slots (conflict-free; derivation below);
+//   * bf16 uses v_mfma_f32_32x32x16_bf16, fp32 (parity mode) uses v_mfma_f32_32x32x2_f32 on the same
+//     byte geometry (a 16-byte unit = 8 bf16 = 4 fp32 channels);
+//   * epilogue fuses bias, InstanceNorm statistics (wave-shuffle + fp32 atomics), skip-gradient
+//     accumulation, and tanh + NCHW store for the generator head.
+#include "common.h"
+#include "pack_math.h"
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA wrappers: one "k-substep" consumes one 16-byte unit per lane of A and of B.
+// bf16: 1 x 32x32x16 (lane (r,h) holds k = 8h..8h+7).  fp32: 4 x 32x32x2 (lane (r,h), element q is k = 4h+q
+// of the 8-channel substep; both operands use the same (h,q) -> channel map so any consistent order is exact).
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+// Tile pixel of MFMA row `row` (0..31) of M-subtile `ms` (0..3):  ty = 2*ms + (row & 1), tx = row >> 1.
+// With row pitch P = 24 pixels the pixel index (ty*P + tx) of the 16 lanes of every ds_read_b128 lane group
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) is distinct mod 16, and the pixel stride is an odd multiple of
+// 16 B (80 / 48 / 16), so the 16 lanes land on 16 distinct 16-byte slots of the 256-byte bank row.
+
+// ---------------------------------------------------------------------------------------------------
+// forward-type gather GEMM
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int MT, int NT, int WM, int WN>
+__global__ void __launch_bounds__(256)
+tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __restrict__ wp, T* out,
+                 const float* __restrict__ bias, float* stats, float* out_nchw,
+                 int flags, int NB32, int nblkN, int buf_bytes, int total_sub) {
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WM * MT == 4, "tile is 4 M-subtiles (128 pixels)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ES = sizeof(T);
+  constexpr int UE = 16 / ES;
+  constexpr int P = TFC_LDS_P;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, r = lane & 31;
+
+  const int PB = tfc_pb(d.Cin_pad, ES);
+  const int UPP = PB >> 4;
+  const int upp_shift = (UPP == 4) ? 2 : (UPP == 2 ? 1 : 0);
+  const int PS = tfc_ps(PB);
+  const int CK = PB / ES;
+  const int nchunks = (d.Cin_pad * ES) / PB;
+  const int nst = nchunks * d.nplanes;
+
+  const int bid = tfc_xcd_remap(blockIdx.x, gridDim.x);
+  const int nb_blk = bid % nblkN;
+  int tile = bid / nblkN;
+  const int txb = tile % d.tiles_x; tile /= d.tiles_x;
+  const int tyb = tile % d.tiles_y;
+  const int img = tile / d.tiles_y;
+  const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+  const int nb0 = (nb_blk * WN + wn) * NT;                     // first 32-channel block of this wave
+
+  // A-operand lane base inside a halo buffer
+  const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * PS;
+  const int MSTRIDE = 2 * P * PS;
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+
+  // ---- halo staging helpers (register-staged: zero fill for padding, padded LDS pixel stride) ----
+  const T* in_img = in + (size_t)img * d.IH * d.IW * d.in_pitch;
+  uint4 hv[4];
+  int hoff[4];
+  auto halo_load = [&](int st) {
+    const int cc = st / d.nplanes, pl = st - cc * d.nplanes;
+    const TfcPlane& pd = d.plane[pl];
+    const int nunits = pd.hh * pd.hw * UPP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      hv[i] = make_uint4(0, 0, 0, 0);
+      hoff[i] = -1;
+      if (idx < nunits) {
+        const int pix = idx >> upp_shift, g = idx & (UPP - 1);
+        const int hy = pix / pd.hw, hx = pix - hy * pd.hw;
+        hoff[i] = (hy * P + hx) * PS + g * 16;
+        const int y = (a0 + pd.dy0 + hy) * d.SS + pd.py;
+        const int x = (b0 + pd.dx0 + hx) * d.SS + pd.px;
+        if (y >= 0 && y < d.IH && x >= 0 && x < d.IW)
+          hv[i] = *reinterpret_cast<const uint4*>(in_img + ((size_t)(y * d.IW + x)) * d.in_pitch + cc * CK + g * UE);
+      }
+    }
+  };
+  auto halo_store = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (hoff[i] >= 0) *reinterpret_cast<uint4*>(buf + hoff[i]) = hv[i];
+  };
+
+  // ---- weight stream ----
+  const uint4* wlane = wp + (size_t)nb0 * 64 + lane;
+  const size_t wstep = (size_t)NB32 * 64;
+  auto loadB = [&](int gs, uint4 (&b)[NT]) {
+    const int g = gs < total_sub ? gs : total_sub - 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = wlane[(size_t)g * wstep + nt * 64];
+  };
+
+  uint4 b0r[NT], b1r[NT];
+  loadB(0, b0r);
+  loadB(1, b1r);
+  halo_load(0);
+  halo_store(smem);
+  __syncthreads();
+
+  int gs = 0;
+  for (int st = 0; st < nst; ++st) {
+    const bool more = (st + 1) < nst;
+    if (more) halo_load(st + 1);
+    const unsigned char* buf = smem + (st & 1) * buf_bytes + laneBase;
+    const int pl = st % d.nplanes;
+    const TfcPlane& pd = d.plane[pl];
+    const int nsub = tfc_nsub(pd.ntaps, PB);                    // even by construction
+    for (int s = 0; s < nsub; s += 2) {
+      // ---- substep s (weights in b0r) ----
+      {
+        const int u0 = 2 * s, u1 = u0 + 1;
+        const int t0 = u0 >> upp_shift, t1 = u1 >> upp_shift;
+        const int off0 = (pd.tap_dy[t0] * P + pd.tap_dx[t0]) * PS + (u0 & (UPP - 1)) * 16;
+        const int off1 = (pd.tap_dy[t1] * P + pd.tap_dx[t1]) * PS + (u1 & (UPP - 1)) * 16;
+        const int off = h ? off1 : off0;
+        uint4 a[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const uint4*>(buf + off + mi * MSTRIDE);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mi], b0r[nt], acc[mi][nt]);
+        loadB(gs + 2, b0r);
+      }
+      // ---- substep s+1 (weights in b1r) ----
+      {
+        const int u0 = 2 * s + 2, u1 = u0 + 1;
+        const int t0 = u0 >> upp_shift, t1 = u1 >> upp_shift;
+        const int off0 = (pd.tap_dy[t0] * P + pd.tap_dx[t0]) * PS + (u0 & (UPP - 1)) * 16;
+        const int off1 = (pd.tap_dy[t1] * P + pd.tap_dx[t1]) * PS + (u1 & (UPP - 1)) * 16;
+        const int off = h ? off1 : off0;
+        uint4 a[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const uint4*>(buf + off + mi * MSTRIDE);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mi], b1r[nt], acc[mi][nt]);
+        loadB(gs + 3, b1r);
+      }
+      gs += 2;
+    }
+    if (more) halo_store(smem + ((st + 1) & 1) * buf_bytes);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const float* bias_p = (flags & TFC_EP_BIAS) ? bias : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (nb0 + nt) * 32 + r;
+    const bool nok = n < d.Nout;
+    const float bv = (bias_p && nok) ? bias_p[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+        const int ty = 2 * (wm * MT + mi) + (row & 1), tx = row >> 1;
+        const int a = a0 + ty, b = b0 + tx;
+        const bool ok = nok && a < d.GH && b < d.GW;
+        float v = acc[mi][nt][j] + bv;
+        if (ok) {
+          const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+          if (flags & TFC_EP_TANH_NCHW) {
+            out_nchw[(((size_t)img * d.Nout + n) * d.OH + oy) * d.OW + ox] = tanhf(v);
+          } else {
+            T* po = out + ((size_t)(img * d.OH + oy) * d.OW + ox) * d.out_pitch + n;
+            if (flags & TFC_EP_ACCUM) v += ElemTraits<T>::ld(po);
+            ElemTraits<T>::st(po, v);
+          }
+          s1 += v; s2 += v * v;
+        }
+      }
+    }
+    if (flags & TFC_EP_STATS) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0 && nok) {
+        atomicAdd(&stats[((size_t)img * d.Nout + n) * 2 + 0], s1);
+        atomicAdd(&stats[((size_t)img * d.Nout + n) * 2 + 1], s2);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight-gradient GEMM:  dWacc[slot][n][c] += sum_pixels dO[pixel][n] * in[src(pixel, tap)][c]
+//   rows = n (64 per workgroup = 2 MFMA row blocks), cols = c (32 per workgroup), K = the 128 pixels of a tile;
+//   wave w owns taps {w*TPW .. w*TPW+TPW-1}; a workgroup walks a strided subset of the pixel tiles (split-K) and
+//   flushes with fp32 atomics (each wave-instruction adds two contiguous 128-B row segments).
+//   bf16: both operands are K(pixel)-strided in LDS, fetched with ds_read_b64_tr_b16 (hardware transpose);
+//   fp32: 32x32x2 operands are one dword per lane, plain ds_read_b32.
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct WgradFrag;
+
+template <typename T, int TPW>
+__global__ void __launch_bounds__(256)
+tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restrict__ in, float* dwacc,
+                 int Nn_pad, int Nn_real, int Cw_real, int nbw, int ncb, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ES = sizeof(T);
+  constexpr int UE = 16 / ES;
+  constexpr int UPN = 32 / UE;                                   // 16-B units per 32 channels
+  constexpr int ROWB = 32 * ES;                                  // bytes per LDS row (32 channels)
+  constexpr int DO_BYTES = 2 * 128 * ROWB;
+  constexpr int HALO_BYTES = TFC_MAX_HH * TFC_MAX_HW * ROWB;
+  constexpr int BUF_BYTES = DO_BYTES + HALO_BYTES;
+  constexpr bool PREFETCH = (ES == 2);
+  constexpr int NDO = (2 * 128 * UPN) / 256;                     // dO units per thread (4 bf16 / 8 fp32)
+  constexpr int NHA = (TFC_MAX_HH * TFC_MAX_HW * UPN + 255) / 256;  // halo units per thread (4 / 7)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TfcPlane& pd = d.plane[0];
+
+  const int bid = tfc_xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % (nbw * ncb);
+  const int sp = bid / (nbw * ncb);
+  const int cb = pair % ncb, nb = pair / ncb;
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+
+  f32x16_t acc[TPW][2];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[ti][ni][j] = 0.f;
+
+  uint4 vdo[NDO], vha[NHA];
+  auto tile_load = [&](int tl) {
+    int t = tl;
+    const int txb = t % d.tiles_x; t /= d.tiles_x;
+    const int tyb = t % d.tiles_y;
+    const int img = t / d.tiles_y;
+    const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) {
+      const int idx = tid + i * 256;
+      const int g = idx % UPN, px = (idx / UPN) & 127, ni = idx / (UPN * 128);
+      const int a = a0 + (px >> 4), b = b0 + (px & 15);
+      const int n0 = nb * 64 + ni * 32 + g * UE;
+      vdo[i] = make_uint4(0, 0, 0, 0);
+      if (a < d.GH && b < d.GW && n0 < Nn_pad) {
+        const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+        vdo[i] = *reinterpret_cast<const uint4*>(dO + ((size_t)(img * d.OH + oy) * d.OW + ox) * d.out_pitch + n0);
+      }
+    }
+    const int nunits = pd.hh * pd.hw * UPN;
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;
+      vha[i] = make_uint4(0, 0, 0, 0);
+      if (idx < nunits) {
+        const int g = idx % UPN, pix = idx / UPN;
+        const int hy = pix / pd.hw, hx = pix - hy * pd.hw;
+        const int y = (a0 + pd.dy0 + hy) * d.SS + pd.py;
+        const int x = (b0 + pd.dx0 + hx) * d.SS + pd.px;
+        const int c0 = cb * 32 + g * UE;
+        if (y >= 0 && y < d.IH && x >= 0 && x < d.IW && c0 < d.Cin_pad)
+          vha[i] = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch + c0);
+      }
+    }
+  };
+  auto tile_store = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) {
+      const int idx = tid + i * 256;                             // == (ni*128 + px)*UPN + g : the LDS image order
+      *reinterpret_cast<uint4*>(buf + idx * 16) = vdo[i];
+    }
+    const int nunits = pd.hh * pd.hw * UPN;
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;                             // == pix*UPN + g
+      if (idx < nunits) *reinterpret_cast<uint4*>(buf + DO_BYTES + idx * 16) = vha[i];
+    }
+  };
+
+  // lane decode for the transposing reads (bf16) / dword reads (fp32)
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trLane = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;    // bf16 only
+
+  auto compute = [&](const unsigned char* buf) {
+    const unsigned char* dob = buf;
+    const unsigned char* hab = buf + DO_BYTES;
+    if constexpr (ES == 2) {
+#pragma unroll 2
+      for (int kt = 0; kt < 8; ++kt) {
+        uint4 a[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const unsigned char* pa = dob + ni * 128 * ROWB + kt * 16 * ROWB + trLane;
+          s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, pa));
+          s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, pa + 4 * ROWB));
+          a[ni].x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+          a[ni].y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+          a[ni].z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+          a[ni].w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+        }
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+          const int tap = wave * TPW + ti;
+          if (tap < pd.ntaps) {                                  // wave-uniform
+            const unsigned char* pb = hab + ((kt + pd.tap_dy[tap]) * pd.hw + pd.tap_dx[tap]) * ROWB + trLane;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, pb));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, pb + 4 * ROWB));
+            uint4 b;
+            b.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+            b.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+            b.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+            b.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[ti][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ni]),
+                                                                     __builtin_bit_cast(bf16x8_t, b), acc[ti][ni], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      const int r = lane & 31, kh = lane >> 5;
+      for (int kk = 0; kk < 64; ++kk) {
+        const int px = 2 * kk + kh;
+        float a[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) a[ni] = *reinterpret_cast<const float*>(dob + (ni * 128 + px) * ROWB + r * 4);
+        const int ty = px >> 4, tx = px & 15;
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+          const int tap = wave * TPW + ti;
+          if (tap < pd.ntaps) {
+            const float b = *reinterpret_cast<const float*>(hab + ((ty + pd.tap_dy[tap]) * pd.hw + tx + pd.tap_dx[tap]) * ROWB + r * 4);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[ti][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ni], b, acc[ti][ni], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  if constexpr (PREFETCH) {
+    int tl = sp;
+    int cur = 0;
+    if (tl < ntiles) { tile_load(tl); tile_store(smem); }
+    __syncthreads();
+    for (; tl < ntiles; tl += nsplit) {
+      const bool more = (tl + nsplit) < ntiles;
+      if (more) tile_load(tl + nsplit);
+      compute(smem + cur * BUF_BYTES);
+      if (more) tile_store(smem + (cur ^ 1) * BUF_BYTES);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    for (int tl = sp; tl < ntiles; tl += nsplit) {
+      tile_load(tl);
+      tile_store(smem);
+      __syncthreads();
+      compute(smem);
+      __syncthreads();
+    }
+  }
+
+  // ---- flush ----
+  const int c = cb * 32 + (lane & 31);
+  const int hrow = lane >> 5;
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int tap = wave * TPW + ti;
+    if (tap < pd.ntaps) {
+      const int slot = pd.tap_slot[tap];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int n = nb * 64 + ni * 32 + (j & 3) + 8 * (j >> 2) + 4 * hrow;
+          if (n < Nn_real && c < Cw_real)
+            atomicAdd(&dwacc[((size_t)slot * Nn_real + n) * Cw_real + c], acc[ti][ni][j]);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing: torch fp32 weight -> operand stream  wp[((gs*NB32 + nb)*64 + lane)] (16 bytes each)
+//   gs enumerates (chunk, plane, k-substep); lane = (rn, h); unit u = 2*s + h; tap = u / UPP; g = u % UPP;
+//   element e <-> channel c = chunk*CK + g*UE + e;  value = W[n*sn + c*sc + slot(tap)] * (*scale)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_pack_w_kernel(const TfcGather d, const float* __restrict__ w, const float* __restrict__ scale_ptr,
+                  uint4* __restrict__ wp, int NB32, int Nreal, int Creal, long long sn, long long sc, int total_units) {
+  constexpr int ES = sizeof(T);
+  constexpr int UE = 16 / ES;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total_units) return;
+  int n, slot, c0;
+  tfc_pack_locate(d, ES, NB32, idx, &n, &slot, &c0);
+  const float scale = scale_ptr ? *scale_ptr : 1.f;
+  float v[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) {
+    const int c = c0 + e;
+    v[e] = (n < Nreal && c < Creal && slot >= 0) ? w[(long long)n * sn + (long long)c * sc + slot] * scale : 0.f;
+  }
+  wp[idx] = pack16<T>(v);
+}
+
+// fp32 accumulator [16 slots][Nn][Cw] -> torch-layout gradient  grad[n*sn + c*sc + slot]
+__global__ void __launch_bounds__(256)
+tfc_wgrad_finish_kernel(const float* __restrict__ acc, float* __restrict__ grad, int Nn, int Cw,
+                        long long sn, long long sc, int accumulate, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int slot = idx & 15;
+  const int rest = idx >> 4;
+  const int c = rest % Cw, n = rest / Cw;
+  const float v = acc[((size_t)slot * Nn + n) * Cw + c];
+  float* g = grad + (long long)n * sn + (long long)c * sc + slot;
+  *g = accumulate ? (*g + v) : v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host launchers (internal C++ API used by api.hip)
+// ---------------------------------------------------------------------------------------------------
+int tfc_total_substeps(const TfcGather& d, int es) {
+  const int PB = tfc_pb(d.Cin_pad, es);
+  int per_chunk = 0;
+  for (int pl = 0; pl < d.nplanes; ++pl) per_chunk += tfc_nsub(d.plane[pl].ntaps, PB);
+  return per_chunk * ((d.Cin_pad * es) / PB);
+}
+int tfc_nb32(int nout) { return (nout + 31) / 32; }
+// NB32 of the packed stream is rounded up to the widest workgroup N extent in use (4 blocks) so every config can read it
+int tfc_nb32_padded(int nout) { int nb = tfc_nb32(nout); return nb <= 1 ? 1 : (nb <= 2 ? 2 : (nb + 3) / 4 * 4); }
+size_t tfc_packed_bytes(const TfcGather& d, int es) {
+  return (size_t)tfc_total_substeps(d, es) * tfc_nb32_padded(d.Nout) * 64 * 16;
+}
+
+template <typename T>
+static hipError_t launch_pack_t(const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal,
+                                long long sn, long long sc, hipStream_t st) {
+  const int NB32 = tfc_nb32_padded(d.Nout);
+  const int total = tfc_total_substeps(d, sizeof(T)) * NB32 * 64;
+  hipLaunchKernelGGL((tfc_pack_w_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, st, d, w, scale, (uint4*)wp, NB32,
+                     Nreal, Creal, sn, sc, total);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal,
+                           long long sn, long long sc, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? launch_pack_t<bf16_t>(d, w, scale, wp, Nreal, Creal, sn, sc, st)
+                           : launch_pack_t<float>(d, w, scale, wp, Nreal, Creal, sn, sc, st);
+}
+
+template <typename T, int MT, int NT, int WM, int WN>
+static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
+                                   float* stats, float* out_nchw, int flags, hipStream_t st) {
+  constexpr int ES = sizeof(T);
+  const int NB32 = tfc_nb32_padded(d.Nout);
+  const int per_blk = NT * WN;
+  const int nblkN = (tfc_nb32(d.Nout) + per_blk - 1) / per_blk;
+  int maxhh = 0;
+  for (int pl = 0; pl < d.nplanes; ++pl) maxhh = d.plane[pl].hh > maxhh ? d.plane[pl].hh : maxhh;
+  const int PS = tfc_ps(tfc_pb(d.Cin_pad, ES));
+  const int buf_bytes = maxhh * TFC_LDS_P * PS;
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+  const int total_sub = tfc_total_substeps(d, ES);
+  hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN>), dim3(ntiles * nblkN), dim3(256), 2 * buf_bytes, st, d,
+                     (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, flags, NB32, nblkN, buf_bytes, total_sub);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
+                                 float* stats, float* out_nchw, int flags, hipStream_t st) {
+  const int nb = tfc_nb32(d.Nout);
+  if (nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if (nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+}
+hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
+                            float* stats, float* out_nchw, int flags, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? launch_igemm_t<bf16_t>(d, in, wp, out, bias, stats, out_nchw, flags, st)
+                           : launch_igemm_t<float>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+}
+
+template <typename T>
+static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad, int Nn_real,
+                                 int Cw_real, hipStream_t st) {
+  constexpr int ES = sizeof(T);
+  const int nbw = (Nn_pad + 63) / 64, ncb = (d.Cin_pad + 31) / 32;
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+  // split-K over pixel tiles: aim at ~3 workgroups per CU, at least 2 tiles per workgroup where possible
+  int nsplit = (768 + nbw * ncb - 1) / (nbw * ncb);
+  if (nsplit > ntiles) nsplit = ntiles;
+  if (nsplit < 1) nsplit = 1;
+  const int lds = (2 * 128 * 32 * ES + TFC_MAX_HH * TFC_MAX_HW * 32 * ES) * (ES == 2 ? 2 : 1);
+  const dim3 grid(nbw * ncb * nsplit);
+  if (d.plane[0].ntaps <= 4)
+    hipLaunchKernelGGL((tfc_wgrad_kernel<T, 1>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, Nn_pad,
+                       Nn_real, Cw_real, nbw, ncb, nsplit);
+  else
+    hipLaunchKernelGGL((tfc_wgrad_kernel<T, 4>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, Nn_pad,
+                       Nn_real, Cw_real, nbw, ncb, nsplit);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad,
+                            int Nn_real, int Cw_real, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? launch_wgrad_t<bf16_t>(d, dO, in, dwacc, Nn_pad, Nn_real, Cw_real, st)
+                           : launch_wgrad_t<float>(d, dO, in, dwacc, Nn_pad, Nn_real, Cw_real, st);
+}
+hipError_t tfc_launch_wgrad_finish(const float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
+                                   int accumulate, hipStream_t st) {
+  const int total = Nn * Cw * 16;
+  hipLaunchKernelGGL(tfc_wgrad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, acc, grad, Nn, Cw, sn, sc,
+                     accumulate, total);
+  return hipGetLastError();
+}

@@ -1,0 +1,176 @@
+// Loss heads of the PATCH-16 training step (gfx950).
+//   triplet16 : the 16-patch "contrastive" head  (reference TFCGAN_multigpu_patchFFT_16P.py:75, :558-583)
+//   spectrum  : ToPILImage -> convert("L") -> np.fft.rfft2 -> fftshift -> |.|, atan2  (reference :271-319)
+//   l1 mean   : nn.L1Loss over amplitude / phase arrays (reference :323-375)
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// 16-patch triplet.  Patch k (0-based) = rows 64*(k/4).., cols 64*(k%4)..  (make_16_patches, reference :227-253;
+// first flat NCHW index of patch k = 64*(k%4) + 16384*(k/4)).  F.triplet_margin_loss(margin 1, p 2, eps 1e-6):
+//   d(x,y) = || x - y + eps ||_2 over the LAST dim (one 64-pixel patch row); loss_k = mean_{n,c,row} max(1 + d_ap - d_an, 0)
+//   total = (1/16) sum_k loss_k.  One wave per patch row: lane = pixel, wave-shuffle reductions.
+// grad wrt anchor (fake):  [hinge>0] * ((a-p+eps)/d_ap - (a-n+eps)/d_an) * scale
+// ---------------------------------------------------------------------------------------------------
+struct NegIdx { int r[16]; };
+
+__global__ void __launch_bounds__(256)
+tfc_triplet16_kernel(const float* __restrict__ fake, const float* __restrict__ real, const NegIdx neg, int N, int C,
+                     float margin, float eps, float* loss, float* dfake, float gscale) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const long long nrows = (long long)N * C * 256 * 4;
+  const float scale = 1.f / (16.f * (float)N * (float)C * 64.f);
+  float lsum = 0.f;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
+    const int kx = (int)(row & 3);
+    const long long r2 = row >> 2;
+    const int y = (int)(r2 & 255);
+    const long long nc = r2 >> 8;                                // n*C + c
+    const int k = (y >> 6) * 4 + kx;
+    const int rk = neg.r[k];
+    const size_t plane = (size_t)nc * 65536;
+    const size_t ia = plane + (size_t)y * 256 + kx * 64 + lane;
+    const size_t in_ = plane + (size_t)((rk >> 2) * 64 + (y & 63)) * 256 + (rk & 3) * 64 + lane;
+    const float a = fake[ia], p = real[ia], ng = real[in_];
+    const float dp = a - p + eps, dn = a - ng + eps;
+    const float sp = wave_sum(dp * dp), sn = wave_sum(dn * dn);
+    const float dap = sqrtf(sp), dan = sqrtf(sn);
+    const float hinge = margin + dap - dan;
+    if (hinge > 0.f) {
+      lsum += hinge;                                             // identical on all lanes
+      if (dfake) {
+        const float g = (dap > 0.f ? dp / dap : 0.f) - (dan > 0.f ? dn / dan : 0.f);
+        dfake[ia] = g * scale * gscale;
+      }
+    } else if (dfake) {
+      dfake[ia] = 0.f;
+    }
+  }
+  if (lane == 0) red[w] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Spectrum of an S x S window of an NCHW fp32 image in [-1,1]:
+//   u8 = (uint8) trunc(x*255)  (wraps mod 256 exactly like tensor.mul(255).byte());  L = (19595 R + 38470 G + 7471 B + 32768) >> 16
+//   F = rfft2(L)  (S x (S/2+1)),  amp = |F|, pha = atan2(Im, Re); optional fftshift of both axes on store.
+// Direct DFT in LDS with an exact sincospi twiddle table: rows (real input) then columns. A workgroup owns one window
+// and a group of KG output columns, so S=256 (GLO-16) fits LDS as well as S=64 (PATCH-16).
+// The four self-conjugate bins have Im forced to +0 (numpy's pocketfft yields exact zeros there).
+// window w -> (n = w / wins_per_img, k = w % wins_per_img), origin row (k / wins_x)*S, col (k % wins_x)*S.
+// ---------------------------------------------------------------------------------------------------
+template <int S, int KG>
+__global__ void __launch_bounds__(256)
+tfc_spectrum_kernel(const float* __restrict__ img, long long bs, long long cs, int rs, int C, int wins_x, int wins_per_img,
+                    float* __restrict__ amp, float* __restrict__ pha, int shift) {
+  constexpr int NB = S / 2 + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lum = smem;                                     // S*S bytes
+  float* tw = reinterpret_cast<float*>(smem + S * S);            // 2*S floats (cos, sin)
+  float* R = tw + 2 * S;                                         // S*KG*2 floats
+  const int w = blockIdx.x;
+  const int kx0 = blockIdx.y * KG;
+  const int n = w / wins_per_img, k = w % wins_per_img;
+  const int y0 = (k / wins_x) * S, x0 = (k % wins_x) * S;
+  const float* base = img + (size_t)n * bs + (size_t)y0 * rs + x0;
+  for (int i = threadIdx.x; i < S * S; i += 256) {
+    const int y = i / S, x = i % S;
+    int q[3];
+    for (int c = 0; c < 3; ++c) {
+      const float v = base[(size_t)(C == 1 ? 0 : c) * cs + (size_t)y * rs + x] * 255.f;
+      q[c] = ((int)v) & 255;
+    }
+    lum[i] = (unsigned char)((19595 * q[0] + 38470 * q[1] + 7471 * q[2] + 32768) >> 16);
+  }
+  for (int i = threadIdx.x; i < S; i += 256) {
+    float sn, cn;
+    sincospif(2.f * (float)i / (float)S, &sn, &cn);
+    tw[2 * i] = cn; tw[2 * i + 1] = sn;
+  }
+  __syncthreads();
+  // rows: R[y][kk] = sum_x L[y][x] * exp(-2 pi i x kx / S)
+  for (int o = threadIdx.x; o < S * KG; o += 256) {
+    const int y = o / KG, kk = o % KG, kx = kx0 + kk;
+    float re = 0.f, im = 0.f;
+    if (kx < NB) {
+      for (int x = 0; x < S; ++x) {
+        const int t = (x * kx) & (S - 1);
+        const float v = (float)lum[y * S + x];
+        re += v * tw[2 * t];
+        im -= v * tw[2 * t + 1];
+      }
+    }
+    R[2 * o] = re; R[2 * o + 1] = im;
+  }
+  __syncthreads();
+  // columns: F[ky][kx] = sum_y R[y][kx] * exp(-2 pi i y ky / S)
+  for (int o = threadIdx.x; o < S * KG; o += 256) {
+    const int ky = o / KG, kk = o % KG, kx = kx0 + kk;
+    if (kx >= NB) continue;
+    float re = 0.f, im = 0.f;
+    for (int y = 0; y < S; ++y) {
+      const int t = (y * ky) & (S - 1);
+      const float c = tw[2 * t], s = tw[2 * t + 1];
+      const float rr = R[2 * (y * KG + kk)], ri = R[2 * (y * KG + kk) + 1];
+      re += rr * c + ri * s;                                     // (rr + i ri) * (c - i s)
+      im += ri * c - rr * s;
+    }
+    if ((kx == 0 || kx == S / 2) && (ky == 0 || ky == S / 2)) im = 0.f;
+    int oy = ky, ox = kx;
+    if (shift) { oy = (ky + S / 2) % S; ox = (kx + NB / 2) % NB; }
+    const size_t oi = ((size_t)w * S + oy) * NB + ox;
+    amp[oi] = sqrtf(re * re + im * im);
+    pha[oi] = atan2f(im, re);
+  }
+}
+
+// out[0] += scale * sum |a - b|
+__global__ void __launch_bounds__(256)
+tfc_l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float scale, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += fabsf(a[i] - b[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+// ---------------------------------------------------------------------------------------------------
+hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int* neg_idx, int N, int C, float margin, float eps,
+                                float* loss, float* dfake, float gscale, hipStream_t st) {
+  NegIdx ni;
+  for (int i = 0; i < 16; ++i) ni.r[i] = neg_idx[i];
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (e != hipSuccess) return e;
+  long long nrows = (long long)N * C * 1024;
+  long long nb = (nrows + 3) / 4;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(tfc_triplet16_kernel, dim3((int)nb), dim3(256), 0, st, fake, real, ni, N, C, margin, eps, loss, dfake, gscale);
+  return hipGetLastError();
+}
+
+// S in {64, 256}; windows = N * wins_per_img; amp/pha: [windows][S][S/2+1]
+hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img,
+                               int nwin, float* amp, float* pha, int shift, hipStream_t st) {
+  if (S == 64) {
+    constexpr int KG = 33;
+    const size_t lds = 64 * 64 + 2 * 64 * 4 + 64 * KG * 2 * 4;
+    hipLaunchKernelGGL((tfc_spectrum_kernel<64, KG>), dim3(nwin, 1), dim3(256), lds, st, img, bs, cs, rs, C, wins_x, wins_per_img, amp, pha, shift);
+  } else if (S == 256) {
+    constexpr int KG = 16;
+    const size_t lds = 256 * 256 + 2 * 256 * 4 + 256 * KG * 2 * 4;
+    hipLaunchKernelGGL((tfc_spectrum_kernel<256, KG>), dim3(nwin, (129 + KG - 1) / KG), dim3(256), lds, st, img, bs, cs, rs, C, wins_x, wins_per_img, amp, pha, shift);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st) {
+  long long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(tfc_l1_sum_kernel, dim3((int)nb), dim3(256), 0, st, a, b, n, scale, out);
+  return hipGetLastError();
+}

@@ -1,0 +1,75 @@
+// Shared host/device descriptors of the TFC-GAN gather-GEMM engine (gfx950).
+//
+// Every convolution-shaped op of the PATCH-16 hot path (reference:
+// TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py:102-211 -- Conv2d k4 s1 p1, ConvTranspose2d k4 s2 p1,
+// Upsample+ZeroPad+Conv2d, ZeroPad+Conv2d, and all of their dgrad / wgrad passes) is expressed as one
+// table-driven "gather GEMM":
+//
+//     out[img][a*OS+OOY][b*OS+OOX][n] = sum over planes pl, taps t in pl, channels c of
+//         in[img][(a + dy0[pl] + dy[t])*SS + py[pl]][(b + dx0[pl] + dx[t])*SS + px[pl]][c]
+//           * W[n][slot(pl,t)][c]                       (zero outside the source image)
+//
+// (a,b) runs over a GH x GW "gather grid"; a workgroup owns an 8 x 16 tile of that grid, stages the
+// (8+span) x (16+span) halo of the source once per 64-byte channel chunk in LDS and replays it for
+// every tap, so the im2col matrix is never materialised and each source byte crosses HBM/L2 once per
+// chunk instead of once per tap.
+#pragma once
+#include <stdint.h>
+
+#define TFC_TILE_H 8
+#define TFC_TILE_W 16
+#define TFC_LDS_P 24          // halo row pitch in pixels (== 8 mod 16: conflict-free ds_read_b128, see igemm.hip)
+#define TFC_MAX_HH 11         // max halo rows (8 + 3)
+#define TFC_MAX_HW 19         // max halo cols (16 + 3)
+#define TFC_MAX_TAPS 16
+#define TFC_MAX_PLANES 4
+
+#define TFC_DT_BF16 0
+#define TFC_DT_F32 1
+
+// epilogue flags
+#define TFC_EP_BIAS 1
+#define TFC_EP_STATS 2        // accumulate per-(img,channel) sum / sum of squares (InstanceNorm statistics)
+#define TFC_EP_ACCUM 4        // out += result (skip-connection gradient accumulation)
+#define TFC_EP_TANH_NCHW 8    // final layer: tanh, store fp32 NCHW
+
+struct TfcPlane {
+  int dy0, dx0;               // halo origin relative to the tile origin, in plane coordinates
+  int py, px;                 // source = plane*SS + (py,px)
+  int hh, hw;                 // halo rows / cols actually used (<= TFC_MAX_HH / TFC_MAX_HW)
+  int ntaps;
+  int pad_;
+  int tap_dy[TFC_MAX_TAPS];   // tap position inside the halo (>= 0)
+  int tap_dx[TFC_MAX_TAPS];
+  int tap_slot[TFC_MAX_TAPS]; // which 4x4 filter tap (ky*4+kx) of the torch weight this tap multiplies
+};
+
+struct TfcGather {
+  int IH, IW, in_pitch, SS;   // source tensor (NHWC, pitch in elements), source stride 1 or 2
+  int Cin_pad;                // gathered channels, multiple of 8
+  int GH, GW;                 // gather grid per image
+  int tiles_y, tiles_x, nimg;
+  int nplanes;
+  int OH, OW, OS, OOY, OOX;   // output tensor dims, output stride / offset (sub-pixel phases)
+  int out_pitch, Nout;        // output pixel pitch (elements), real output channels
+  struct TfcPlane plane[TFC_MAX_PLANES];
+};
+
+// Derived constants (host and device agree through these helpers).
+static inline __host__ __device__ int tfc_pb(int cin_pad, int es) { int b = cin_pad * es; return b < 64 ? b : 64; }  // chunk bytes per pixel
+static inline __host__ __device__ int tfc_ps(int pb) { return pb == 16 ? 16 : pb + 16; }                             // LDS pixel stride (bytes)
+static inline __host__ __device__ int tfc_nsub(int ntaps, int pb) { return ntaps * (pb >> 4) / 2; }                  // k-substeps of one plane per chunk
+
+// fused normalisation / activation / blur-pool kernels (elementwise.hip)
+struct ActParams {
+  int N, H, W, C;            // pre-pool tensor dims (x)
+  int Ho, Wo;                // post-pool dims (== H,W when pool == 0 or 1)
+  int x_pitch, o_pitch;      // pixel pitches (elements) of x / of the pooled-side tensor
+  int pool;                  // 0 none, 1 blur stride 1, 2 blur stride 2
+  int norm;                  // apply InstanceNorm using stats
+  float slope;               // LeakyReLU slope (0 => ReLU, 1 => identity)
+  float eps;
+  unsigned drop_thresh24;    // 0 => no dropout
+  unsigned seed;
+  float drop_scale;
+};

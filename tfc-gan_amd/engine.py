@@ -1,0 +1,112 @@
+"""The PATCH-16 training step (reference TFCGAN_multigpu_patchFFT_16P.py:545-638) as one engine object.
+
+    G step : fake = G(A); pf = D(fake, A); pr = D(B, A)
+             loss_G = 0.5 * BCE(pf - pr.detach(), 0.9) + triplet16(fake, B, neg_idx) + 0.01 * patchFFT(fake, B)   (:554-607)
+             backward through D (input gradient only) and G; Adam(G)
+    D step : pr = D(B, A); pf = D(fake.detach(), A); loss_D = 0.5 * [BCE(pr - pf, 0.9) + BCE(pf - pr, 0)]          (:623-630)
+             backward; Adam(D)
+
+Scope notes: LPIPS (:598) and the temperature head (:587-595) are not part of this path (LPIPS needs
+VGG weights that cannot be fetched offline; the temperature term has zero gradient); `extra_loss_G` lets a caller add
+them.  The FFT term carries no gradient in the reference (tensor -> PIL -> numpy, :300-302) and none here.  bf16 needs no
+GradScaler (:518); the reference's wasted D weight-gradients during the G step (:619 zeroes them) are simply not computed.
+"""
+import math
+
+import torch
+
+from . import nets, ops, parallel
+from .losses import global_fft_loss, patch_fft_loss
+from .ops import DT_BF16
+
+
+class TrainStep:
+    def __init__(self, generator, discriminator, lr=2e-4, b1=0.5, b2=0.999, eps=1e-8, compute_dtype=torch.bfloat16,
+                 fft_mode="patch", seed=0, bucket_bytes=32 << 20, lambda_gan=0.5, lambda_fft=0.01, lambda_trip=1.0):
+        dev = next(generator.parameters()).device
+        if dev.type != "cuda":
+            raise ops._lib.TfcError("TrainStep needs the modules on a CUDA/HIP device (no CPU fallback)")
+        self.dev, self.dt = dev, ops.dt_of(compute_dtype)
+        self.G_mod, self.D_mod = generator, discriminator
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        self.lambda_gan, self.lambda_fft, self.lambda_trip = lambda_gan, lambda_fft, lambda_trip
+        self.fft_mode = fft_mode
+        self.seed = seed
+        self.step_no = 0
+        # flat fp32 parameter / gradient / Adam buffers in backward order; module parameters become views of them, so
+        # state_dict()/load_state_dict() keep working and stay in the reference's layout.
+        self.gflat = parallel.FlatParams(generator.named_core_params(), nets.g_backward_order(), dev)
+        self.dflat = parallel.FlatParams(discriminator.named_core_params(), nets.d_backward_order(), dev)
+        for mod, flat in ((generator, self.gflat), (discriminator, self.dflat)):
+            named = dict(mod.named_parameters())
+            for k in flat.order:
+                named[k].data = flat.views[k]
+                named[k].grad = flat.grad_views[k]
+        parallel.broadcast_flat(self.gflat)
+        parallel.broadcast_flat(self.dflat)
+        self.dbufs = discriminator.named_core_buffers()
+        parallel.broadcast_tensors(list(self.dbufs.values()))
+        self.gm, self.gv = torch.zeros_like(self.gflat.data), torch.zeros_like(self.gflat.data)
+        self.dm, self.dv = torch.zeros_like(self.dflat.data), torch.zeros_like(self.dflat.data)
+        self.g_reduce = parallel.BucketReducer(self.gflat, bucket_bytes)
+        self.d_reduce = parallel.BucketReducer(self.dflat, bucket_bytes)
+        self.G = nets.GeneratorCore(self.dt, generator.channels)
+        self.G.set_params(self.gflat.views)
+        self.D = nets.DiscriminatorCore(self.dt, discriminator.channels)
+        self.D.set_params(self.dflat.views, self.dbufs)
+        self.G.repack()
+        self.D.repack()
+        self.last = {}
+
+    def _gl(self, like):
+        return ops.new_act(like.N, like.H, like.W, 8, self.dt, self.dev, zero=True)
+
+    def step(self, real_A, real_B, neg_idx=None, extra_loss_G=None):
+        """real_A, real_B: fp32 NCHW [N,3,256,256] in [-1,1] on the GPU (this rank's shard). Returns a dict of device scalars."""
+        dt = self.dt
+        self.step_no += 1
+        t = self.step_no
+        if neg_idx is None:
+            neg_idx = parallel.shared_neg_idx(t, self.seed)
+        drop_seed = (self.seed * 7919 + t * 104729 + parallel.rank() * 1299709) & 0x3FFFFFF
+        train = self.G_mod.training
+        # ---------------- generator step ----------------
+        fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
+        pf, dctx_f = self.D.forward(fake, real_A, power_iter=True, save=True)
+        pr, _ = self.D.forward(real_B, real_A, power_iter=True, save=False)
+        g_pf = self._gl(pf)
+        loss_gan = ops.bce_relativistic(dt, pf, pr, 0, 0.9, da=ops.View(g_pf.t, 1, 0), gscale=self.lambda_gan)
+        loss_trip, g_trip = ops.patch16_triplet(fake, real_B, neg_idx, want_grad=True, gscale=self.lambda_trip)
+        if self.fft_mode == "patch":
+            loss_fft, loss_amp, loss_pha = patch_fft_loss(fake, real_B)
+        else:
+            loss_fft, loss_amp, loss_pha = global_fft_loss(fake, real_B)
+        g_fake = self.D.backward(dctx_f, g_pf, grads=None, need_input_grad=True)
+        ops.axpby(g_fake, g_fake, g_trip, 1.0, 1.0)
+        if extra_loss_G is not None:                              # optional pluggable term (LPIPS / temperature): returns (loss, dfake)
+            extra, g_extra = extra_loss_G(fake, real_B)
+            ops.axpby(g_fake, g_fake, g_extra, 1.0, 1.0)
+        self.G.backward(gctx, g_fake, self.gflat.grad_views, hook=self.g_reduce.ready)
+        gscale = self.g_reduce.finish()
+        ops.adam_step(self.gflat.data, self.gflat.grad, self.gm, self.gv, self.lr, self.b1, self.b2, self.eps, t, gscale)
+        self.G.repack()
+        # ---------------- discriminator step ----------------
+        pr2, dctx_r = self.D.forward(real_B, real_A, power_iter=True, save=True)
+        pf2, dctx_f2 = self.D.forward(fake, real_A, power_iter=True, save=True)
+        g_pr, g_pf2 = self._gl(pr2), self._gl(pf2)
+        loss_d = ops.bce_relativistic(dt, pr2, pf2, 1, 0.9, 0.0, da=ops.View(g_pr.t, 1, 0), db=ops.View(g_pf2.t, 1, 0))
+        self.D.backward(dctx_r, g_pr, grads=self.dflat.grad_views, need_input_grad=False, accumulate=False)
+        self.D.backward(dctx_f2, g_pf2, grads=self.dflat.grad_views, need_input_grad=False, accumulate=True, hook=self.d_reduce.ready)
+        dscale = self.d_reduce.finish()
+        ops.adam_step(self.dflat.data, self.dflat.grad, self.dm, self.dv, self.lr, self.b1, self.b2, self.eps, t, dscale)
+        self.D.repack()
+        loss_g = self.lambda_gan * loss_gan + loss_trip + self.lambda_fft * loss_fft
+        self.last = {"loss_G": loss_g.reshape(()), "loss_GAN_g": loss_gan.reshape(()), "loss_triplet_patch": loss_trip.reshape(()),
+                     "loss_FFT": loss_fft.reshape(()), "loss_Amp": loss_amp, "loss_Pha": loss_pha, "loss_D": loss_d.reshape(()),
+                     "fake_B": fake}
+        return self.last
+
+    # algorithmic work of one step per image: conv / convT MACs x 2
+    G_FWD_GFLOP = 23.574
+    D_FWD_GFLOP = 13.224
+    STEP_GFLOP = 3 * 23.574 + 4 * 13.224 + 13.224 + 2 * 2 * 13.224

@@ -1,0 +1,313 @@
+"""Forward / backward orchestration of the two networks of the PATCH-16 path on the HIP kernels.
+
+`GeneratorCore` mirrors GeneratorUNet (reference TFCGAN_multigpu_patchFFT_16P.py:136-174), `DiscriminatorCore` mirrors
+Discriminator1 (:182-211).  Both work on raw NHWC buffers and hand-written backward chains (no autograd inside); the
+nn.Module mirrors in models.py wrap them in torch.autograd.Function, and engine.py calls them directly.
+
+Skip connections never copy: each UNetUp output and its skip tensor are two channel windows of ONE concat buffer,
+the down path writes its pooled output straight into the skip window, and the transposed convolution reads the whole
+buffer (reference torch.cat, :133).  Gradients mirror that: the convT dgrad writes the whole concat gradient, the
+down path accumulates into its window.
+"""
+import torch
+
+from . import ops
+from .ops import (DT_BF16, OP_CONV, OP_CONVT, OP_PADCONV, OP_UPCONV, View, new_act)
+
+# (name, Cin, Cout, normalize, dropout)  -- reference :140-145
+G_DOWN = [("down1", 3, 64, False, 0.0), ("down2", 64, 128, True, 0.0), ("down3", 128, 256, True, 0.5),
+          ("down4", 256, 512, True, 0.5), ("down5", 512, 512, False, 0.0), ("down6", 512, 512, True, 0.0)]
+# (name, Cin, Cout, dropout, skip = index of the down block concatenated)  -- reference :147-151
+G_UP = [("up1", 512, 512, 0.0, 4), ("up2", 1024, 512, 0.5, 3), ("up3", 1024, 256, 0.5, 2), ("up4", 512, 128, 0.0, 1),
+        ("up5", 256, 64, 0.0, 0)]
+# (index in nn.Sequential, Cin, Cout)  -- reference :194-202
+D_BLOCKS = [(0, 6, 64), (3, 64, 128), (6, 128, 256), (9, 256, 512)]
+
+
+def down_weight_key(name):
+    return f"{name}.model.0.weight"
+
+
+def g_param_names():
+    names = [down_weight_key(n) for n, *_ in G_DOWN] + [f"{n}.model.0.weight" for n, *_ in G_UP]
+    return names + ["final.2.weight", "final.2.bias"]
+
+
+def g_backward_order():
+    """Parameter names in the order their gradients become final during backward (bucket order for DDP)."""
+    return (["final.2.weight", "final.2.bias"] + [f"{n}.model.0.weight" for n, *_ in reversed(G_UP)]
+            + [down_weight_key(n) for n, *_ in reversed(G_DOWN)])
+
+
+def d_param_names():
+    out = []
+    for i, _, _ in D_BLOCKS:
+        out += [f"model.{i}.bias", f"model.{i}.parametrizations.weight.original"]
+    return out + ["model.13.weight"]
+
+
+def d_backward_order():
+    out = ["model.13.weight"]
+    for i, _, _ in reversed(D_BLOCKS):
+        out += [f"model.{i}.parametrizations.weight.original", f"model.{i}.bias"]
+    return out
+
+
+def pooled(h):
+    return (h - 1) // 2 + 1
+
+
+class _Ctx:
+    pass
+
+
+class GeneratorCore:
+    def __init__(self, dt=DT_BF16, channels=3):
+        self.dt = dt
+        self.channels = channels
+        self.params = None
+        self.packed = {}
+        self._ws = None
+
+    # ---- weights ----
+    def set_params(self, params):
+        """params: dict state_dict-key -> fp32 CUDA tensor in torch layout (may be views into a flat buffer)."""
+        self.params = params
+        self.packed = {}
+
+    def repack(self):
+        dt, P = self.dt, self.params
+        for name, cin, cout, _, _ in G_DOWN:
+            w = P[down_weight_key(name)]
+            ent = self.packed.setdefault(name, {})
+            ent["fwd"] = ops.pack_weight(dt, OP_CONV, 0, w, cin, cout, out=ent.get("fwd"))
+            if name != "down1":
+                ent["dgrad"] = ops.pack_weight(dt, OP_CONV, 1, w, cin, cout, out=ent.get("dgrad"))
+        for name, cin, cout, _, _ in G_UP:
+            w = P[f"{name}.model.0.weight"]
+            ent = self.packed.setdefault(name, {})
+            ent["fwd"] = ops.pack_weight(dt, OP_CONVT, 0, w, cin, cout, out=ent.get("fwd"))
+            ent["dgrad"] = ops.pack_weight(dt, OP_CONVT, 1, w, cin, cout, out=ent.get("dgrad"))
+        w = P["final.2.weight"]
+        ent = self.packed.setdefault("final", {})
+        ent["fwd"] = ops.pack_weight(dt, OP_UPCONV, 0, w, 128, self.channels, out=ent.get("fwd"))
+        ent["dgrad"] = ops.pack_weight(dt, OP_UPCONV, 1, w, 128, self.channels, out=ent.get("dgrad"))
+
+    # ---- forward ----
+    def forward(self, x, seed=0, train=True, save=True):
+        """x: fp32 NCHW [N,3,S,S] (S multiple of 64, >= 128). Returns (fake fp32 NCHW in (-1,1), ctx)."""
+        ops.require_gpu(x)
+        if not self.packed:
+            self.repack()
+        dt, dev = self.dt, x.device
+        N, C, S, S2 = x.shape
+        assert C == self.channels and S == S2 and S % 64 == 0 and S >= 128, "GeneratorUNet needs square inputs, S % 64 == 0, S >= 128"
+        ctx = _Ctx()
+        ctx.N, ctx.S, ctx.seed, ctx.train = N, S, seed, train
+        x8 = ops.pack_nhwc8(dt, x)
+        # concat buffers: cat[k] = (up_k output | skip) at the resolution of the skip
+        sizes = [S >> (i + 1) for i in range(6)]                 # pooled sizes of down1..down6: 128,64,32,16,8,4
+        cat = {}
+        for name, cin, cout, _, skip in G_UP:
+            sc = G_DOWN[skip][2]
+            cat[name] = new_act(N, sizes[skip], sizes[skip], cout + sc, dt, dev)
+        d6 = new_act(N, sizes[5], sizes[5], 512, dt, dev)
+        skip_of = {4: "up1", 3: "up2", 2: "up3", 1: "up4", 0: "up5"}
+        ctx.x8, ctx.cat, ctx.d6 = x8, cat, d6
+        ctx.raw, ctx.stats, ctx.dins = [], [], []
+        cur = x8
+        for i, (name, cin, cout, normalize, drop) in enumerate(G_DOWN):
+            h = cur.H
+            raw = new_act(N, h - 1, h - 1, cout, dt, dev)
+            stats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev) if normalize else None
+            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.packed[name]["fwd"], raw, stats=stats)
+            if i < 5:
+                up = skip_of[i]
+                upc = cat[up].C - cout
+                dst = cat[up].sub(upc, cout)
+            else:
+                dst = d6
+            ops.act_fwd(dt, raw, dst, stats=stats, slope=0.2, pool=2, drop_p=drop if train else 0.0, seed=seed * 64 + i)
+            ctx.raw.append(raw)
+            ctx.stats.append(stats)
+            ctx.dins.append(cur)
+            cur = dst
+        ctx.blur, ctx.bstats, ctx.uins = [], [], []
+        for j, (name, cin, cout, drop, skip) in enumerate(G_UP):
+            h = cur.H
+            rawT = new_act(N, 2 * h, 2 * h, cout, dt, dev)
+            ops.conv_fwd(dt, OP_CONVT, cur, cin, cout, self.packed[name]["fwd"], rawT)
+            blur = new_act(N, 2 * h, 2 * h, cout, dt, dev)
+            bstats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
+            ops.act_fwd(dt, rawT, blur, stats=None, slope=1.0, pool=1, stats_out=bstats)
+            ops.act_fwd(dt, blur, cat[name].sub(0, cout), stats=bstats, slope=0.0, pool=0, drop_p=drop if train else 0.0,
+                        seed=seed * 64 + 16 + j)
+            ctx.blur.append(blur)
+            ctx.bstats.append(bstats)
+            ctx.uins.append(cur)
+            cur = View(cat[name].t, cat[name].t.shape[3], 0)
+        fake = torch.empty((N, self.channels, S, S), dtype=torch.float32, device=dev)
+        ops.conv_fwd(dt, OP_UPCONV, cur, 128, self.channels, self.packed["final"]["fwd"], None, bias=self.params["final.2.bias"],
+                     out_nchw=fake)
+        ctx.u5 = cur
+        ctx.fake = fake
+        if not save:
+            return fake, None
+        return fake, ctx
+
+    # ---- backward ----
+    def backward(self, ctx, g_fake, grads, hook=None, accumulate=False):
+        """g_fake: fp32 NCHW gradient of the loss wrt fake. grads: dict key -> fp32 tensor (torch layout) that receives the
+        parameter gradients (overwritten, or accumulated when `accumulate`). hook(key) fires when a gradient is final."""
+        dt, N = self.dt, ctx.N
+        dev = g_fake.device
+        ch = self.channels
+        gb = grads["final.2.bias"]
+        if not accumulate:
+            gb.zero_()
+        dyf = ops.tanh_bwd_pack(dt, g_fake.contiguous().float(), ctx.fake, dbias=gb)
+        self._ws = ops.conv_wgrad(dt, OP_UPCONV, ctx.u5, dyf, 128, ch, grads["final.2.weight"], accumulate, self._ws)
+        if hook:
+            hook("final.2.weight")
+            hook("final.2.bias")
+        g_cat = new_act(N, ctx.u5.H, ctx.u5.W, ctx.u5.pitch, dt, dev)
+        ops.conv_dgrad(dt, OP_UPCONV, dyf, N, ctx.u5.H, ctx.u5.W, 128, ch, self.packed["final"]["dgrad"], g_cat)
+        g_skip = [None] * 6                                       # gradient window of d1..d5 (views), g_d6 separately
+        for j in range(4, -1, -1):
+            name, cin, cout, drop, skip = G_UP[j]
+            blur, bstats, uin = ctx.blur[j], ctx.bstats[j], ctx.uins[j]
+            H = blur.H
+            g_out = g_cat.sub(0, cout)
+            g_skip[skip] = g_cat.sub(cout, g_cat.pitch - cout)
+            rstats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
+            dp = drop if ctx.train else 0.0
+            sd = ctx.seed * 64 + 16 + j
+            ops.act_bwd(dt, 1, g_out, blur, N, H, H, cout, None, stats=bstats, slope=0.0, pool=0, drop_p=dp, seed=sd, rstats=rstats)
+            d_blur = new_act(N, H, H, cout, dt, dev)
+            ops.act_bwd(dt, 2, g_out, blur, N, H, H, cout, d_blur, stats=bstats, slope=0.0, pool=0, drop_p=dp, seed=sd, rstats=rstats)
+            d_rawT = new_act(N, H, H, cout, dt, dev)
+            ops.act_bwd(dt, 0, d_blur, None, N, H, H, cout, d_rawT, stats=None, slope=1.0, pool=1)
+            key = f"{name}.model.0.weight"
+            self._ws = ops.conv_wgrad(dt, OP_CONVT, uin, d_rawT, cin, cout, grads[key], accumulate, self._ws)
+            if hook:
+                hook(key)
+            g_in = new_act(N, uin.H, uin.W, uin.pitch, dt, dev)
+            ops.conv_dgrad(dt, OP_CONVT, d_rawT, N, uin.H, uin.W, cin, cout, self.packed[name]["dgrad"], g_in)
+            g_cat = g_in                                          # gradient of the next concat buffer (or of d6 when j == 0)
+        g_cur = g_cat                                             # = gradient of d6
+        for i in range(5, -1, -1):
+            name, cin, cout, normalize, drop = G_DOWN[i]
+            raw, stats, din = ctx.raw[i], ctx.stats[i], ctx.dins[i]
+            Hc = raw.H
+            dp = drop if ctx.train else 0.0
+            sd = ctx.seed * 64 + i
+            d_raw = new_act(N, Hc, Hc, cout, dt, dev)
+            if normalize:
+                rstats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
+                ops.act_bwd(dt, 1, g_cur, raw, N, Hc, Hc, cout, None, stats=stats, slope=0.2, pool=2, drop_p=dp, seed=sd, rstats=rstats)
+                ops.act_bwd(dt, 2, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=stats, slope=0.2, pool=2, drop_p=dp, seed=sd, rstats=rstats)
+            else:
+                ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, drop_p=dp, seed=sd)
+            key = down_weight_key(name)
+            self._ws = ops.conv_wgrad(dt, OP_CONV, din, d_raw, cin, cout, grads[key], accumulate, self._ws)
+            if hook:
+                hook(key)
+            if i > 0:
+                tgt = g_skip[i - 1]                               # window of d_{i} gradient already holding the skip-path part
+                ops.conv_dgrad(dt, OP_CONV, d_raw, N, din.H, din.W, cin, cout, self.packed[name]["dgrad"], tgt, accumulate=True)
+                g_cur = tgt
+        return None
+
+
+class DiscriminatorCore:
+    def __init__(self, dt=DT_BF16, channels=3):
+        self.dt = dt
+        self.channels = channels
+        self.params = None
+        self.buffers = None
+        self.head_packed = {}
+
+    def set_params(self, params, buffers):
+        """params: dict key -> fp32 tensor ('model.{0,3,6,9}.bias', '...parametrizations.weight.original', 'model.13.weight');
+        buffers: dict 'model.{i}.parametrizations.weight.0._u' / '._v' -> fp32 tensors (updated in place)."""
+        self.params, self.buffers = params, buffers
+        self.head_packed = {}
+
+    def repack(self):
+        w = self.params["model.13.weight"]
+        self.head_packed["fwd"] = ops.pack_weight(self.dt, OP_PADCONV, 0, w, 512, 1, out=self.head_packed.get("fwd"))
+        self.head_packed["dgrad"] = ops.pack_weight(self.dt, OP_PADCONV, 1, w, 512, 1, out=self.head_packed.get("dgrad"))
+
+    def forward(self, img_a, img_b, power_iter=True, save=True):
+        """img_a, img_b: fp32 NCHW [N,3,S,S]. Returns (logits View [N,S/16,S/16,pitch 8] channel 0, ctx)."""
+        ops.require_gpu(img_a, img_b)
+        if not self.head_packed:
+            self.repack()
+        dt, dev = self.dt, img_a.device
+        N, C, S, _ = img_a.shape
+        ctx = _Ctx()
+        ctx.N, ctx.S = N, S
+        x8 = ops.pack_nhwc8(dt, img_a, img_b)
+        ctx.ins, ctx.raw, ctx.sn = [], [], []
+        cur = x8
+        for i, cin, cout in D_BLOCKS:
+            W = self.params[f"model.{i}.parametrizations.weight.original"]
+            u = self.buffers[f"model.{i}.parametrizations.weight.0._u"]
+            v = self.buffers[f"model.{i}.parametrizations.weight.0._v"]
+            sigma2 = torch.empty(2, dtype=torch.float32, device=dev)
+            ops.spectral_norm_step(W, u, v, sigma2, power_iter=power_iter)
+            packed = ops.pack_weight(dt, OP_CONV, 0, W, cin, cout, scale=sigma2[1:])
+            h = cur.H
+            raw = new_act(N, h - 1, h - 1, cout, dt, dev)
+            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, packed, raw, bias=self.params[f"model.{i}.bias"])
+            out = new_act(N, pooled(h - 1), pooled(h - 1), cout, dt, dev)
+            ops.act_fwd(dt, raw, out, stats=None, slope=0.2, pool=2)
+            ctx.ins.append(cur)
+            ctx.raw.append(raw)
+            ctx.sn.append((u.clone(), v.clone(), sigma2) if save else None)
+            cur = out
+        logits = new_act(N, cur.H, cur.W, 8, dt, dev, zero=True)
+        ops.conv_fwd(dt, OP_PADCONV, cur, 512, 1, self.head_packed["fwd"], View(logits.t, 1, 0))
+        ctx.p4 = cur
+        return View(logits.t, 1, 0), (ctx if save else None)
+
+    def backward(self, ctx, g_logits, grads=None, need_input_grad=True, accumulate=False, hook=None, ws=None):
+        """g_logits: View [N,h,w,8] (channel 0 = gradient, channels 1..7 zero). grads: dict key -> fp32 tensor or None
+        (skip all weight gradients: generator step). Returns fp32 NCHW gradient of img_a (first argument) or None."""
+        dt, N = self.dt, ctx.N
+        dev = g_logits.t.device
+        gl = View(g_logits.t, 8, 0)
+        if grads is not None:
+            ws = ops.conv_wgrad(dt, OP_PADCONV, ctx.p4, gl, 512, 1, grads["model.13.weight"], accumulate, ws)
+            if hook:
+                hook("model.13.weight")
+        g_cur = new_act(N, ctx.p4.H, ctx.p4.W, 512, dt, dev)
+        ops.conv_dgrad(dt, OP_PADCONV, gl, N, ctx.p4.H, ctx.p4.W, 512, 1, self.head_packed["dgrad"], g_cur)
+        g_in = None
+        for bi in range(3, -1, -1):
+            i, cin, cout = D_BLOCKS[bi]
+            raw, xin = ctx.raw[bi], ctx.ins[bi]
+            u, v, sigma2 = ctx.sn[bi]
+            Hc = raw.H
+            d_raw = new_act(N, Hc, Hc, cout, dt, dev)
+            ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2)
+            W = self.params[f"model.{i}.parametrizations.weight.original"]
+            if grads is not None:
+                gbias = grads[f"model.{i}.bias"]
+                if not accumulate:
+                    gbias.zero_()
+                ops.colsum(dt, d_raw, gbias)
+                gsn = torch.empty_like(W)
+                ws = ops.conv_wgrad(dt, OP_CONV, xin, d_raw, cin, cout, gsn, False, ws)
+                ops.spectral_norm_bwd(gsn, W, u, v, sigma2, grads[f"model.{i}.parametrizations.weight.original"], accumulate)
+                if hook:
+                    hook(f"model.{i}.parametrizations.weight.original")
+                    hook(f"model.{i}.bias")
+            if bi > 0 or need_input_grad:
+                packed = ops.pack_weight(dt, OP_CONV, 1, W, cin, cout, scale=sigma2[1:])
+                g_in = new_act(N, xin.H, xin.W, xin.pitch, dt, dev)
+                ops.conv_dgrad(dt, OP_CONV, d_raw, N, xin.H, xin.W, cin, cout, packed, g_in)
+                g_cur = g_in
+        if need_input_grad:
+            return ops.unpack_nchw(dt, g_cur, self.channels, c0=0)
+        return None

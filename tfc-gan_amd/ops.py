@@ -1,0 +1,277 @@
+"""Thin torch-tensor wrappers over the C ABI (include/tfc_gan.h). torch is used for device memory and streams only.
+
+Activations are torch tensors of physical shape [N, H, W, pitch] (NHWC); a `View` names a channel window
+[coff, coff + C) of such a buffer, which is how skip connections share one concat buffer without copies.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import (DT_BF16, DT_F32, EP_ACCUM, EP_BIAS, EP_STATS, EP_TANH_NCHW, OP_CONV, OP_CONVT, OP_PADCONV, OP_UPCONV, check)
+
+
+def lib():
+    return _lib.load()
+
+
+def torch_dtype(dt):
+    return torch.bfloat16 if dt == DT_BF16 else torch.float32
+
+
+def dt_of(dtype):
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    if dtype == torch.float32:
+        return DT_F32
+    raise ValueError(f"compute dtype must be torch.bfloat16 or torch.float32, got {dtype}")
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.TfcError("libtfcgan_hip kernels need CUDA/HIP tensors; got a CPU tensor "
+                                "(there is no CPU fallback in this package)")
+
+
+@dataclass
+class View:
+    """Channel window of an NHWC buffer."""
+    t: torch.Tensor      # [N, H, W, pitch]
+    C: int               # logical channels
+    coff: int = 0
+
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def H(self):
+        return self.t.shape[1]
+
+    @property
+    def W(self):
+        return self.t.shape[2]
+
+    @property
+    def pitch(self):
+        return self.t.shape[3]
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.t.data_ptr() + self.coff * self.t.element_size())
+
+    def sub(self, coff, C):
+        return View(self.t, C, self.coff + coff)
+
+
+def new_act(N, H, W, C, dt, device, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return View(f((N, H, W, C), dtype=torch_dtype(dt), device=device), C)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+OUT_HW = {OP_CONV: lambda h: h - 1, OP_PADCONV: lambda h: h, OP_CONVT: lambda h: 2 * h, OP_UPCONV: lambda h: 2 * h}
+
+
+# ---- convolution family ---------------------------------------------------------------------------------------
+def packed_bytes(dt, op, pas, Cin, Cout):
+    return lib().tfc_conv_packed_bytes(dt, op, pas, Cin, Cout)
+
+
+def pack_weight(dt, op, pas, w, Cin, Cout, scale=None, out=None):
+    """w: torch-layout fp32 weight on the GPU; returns a uint8 tensor holding the MFMA operand stream."""
+    require_gpu(w)
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    nbytes = packed_bytes(dt, op, pas, Cin, Cout)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    assert out.numel() >= nbytes
+    check(lib().tfc_conv_pack(stream_ptr(), dt, op, pas, _p(w), _p(scale), _p(out), Cin, Cout), "tfc_conv_pack")
+    return out
+
+
+def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stats=None, out_nchw=None, flags=0):
+    if bias is not None:
+        flags |= EP_BIAS
+    if stats is not None:
+        flags |= EP_STATS
+    if out_nchw is not None:
+        flags |= EP_TANH_NCHW
+    check(lib().tfc_conv_fwd(stream_ptr(), dt, op, x.ptr, x.pitch, x.N, x.H, x.W, Cin, Cout, _p(packed),
+                             None if y is None else y.ptr, 0 if y is None else y.pitch, _p(bias), _p(stats), _p(out_nchw), flags),
+          "tfc_conv_fwd")
+
+
+def conv_dgrad(dt, op, dy: View, N, H, W, Cin, Cout, packed, dx: View, accumulate=False):
+    check(lib().tfc_conv_dgrad(stream_ptr(), dt, op, dy.ptr, dy.pitch, N, H, W, Cin, Cout, _p(packed), dx.ptr, dx.pitch,
+                               EP_ACCUM if accumulate else 0), "tfc_conv_dgrad")
+
+
+def conv_wgrad(dt, op, x: View, dy: View, Cin, Cout, dw, accumulate=False, ws=None):
+    nbytes = lib().tfc_conv_wgrad_ws_bytes(op, Cin, Cout)
+    if ws is None or ws.numel() * ws.element_size() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
+    assert dw.dtype == torch.float32 and dw.is_contiguous()
+    check(lib().tfc_conv_wgrad(stream_ptr(), dt, op, x.ptr, x.pitch, dy.ptr, dy.pitch, x.N, x.H, x.W, Cin, Cout, _p(ws), _p(dw),
+                               1 if accumulate else 0), "tfc_conv_wgrad")
+    return ws
+
+
+# ---- fused norm / activation / blur-pool ----------------------------------------------------------------------
+def act_fwd(dt, x: View, y: View, stats=None, slope=0.2, pool=0, drop_p=0.0, seed=0, stats_out=None):
+    check(lib().tfc_act_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, x.C, _p(stats), 0 if stats is None else 1, slope, pool,
+                            drop_p, seed & 0xFFFFFFFF, y.ptr, y.pitch, _p(stats_out)), "tfc_act_fwd")
+
+
+def act_bwd(dt, mode, dy: View, x: View, N, H, W, C, dx: View = None, stats=None, slope=0.2, pool=0, drop_p=0.0, seed=0, rstats=None):
+    check(lib().tfc_act_bwd(stream_ptr(), dt, mode, dy.ptr, dy.pitch, None if x is None else x.ptr, 0 if x is None else x.pitch,
+                            N, H, W, C, _p(stats), 0 if stats is None else 1, slope, pool, drop_p, seed & 0xFFFFFFFF, _p(rstats),
+                            None if dx is None else dx.ptr, 0 if dx is None else dx.pitch), "tfc_act_bwd")
+
+
+def dropout_mask(n, drop_p, seed, device):
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    check(lib().tfc_dropout_mask(stream_ptr(), _p(out), n, drop_p, seed & 0xFFFFFFFF), "tfc_dropout_mask")
+    return out
+
+
+# ---- layout plumbing ------------------------------------------------------------------------------------------
+def pack_nhwc8(dt, a, b=None):
+    """NCHW fp32 a [N,Ca,H,W] (and b) -> NHWC with 8 channels."""
+    require_gpu(a, b)
+    a = a.contiguous().float()
+    N, Ca, H, W = a.shape
+    Cb = 0
+    if b is not None:
+        b = b.contiguous().float()
+        Cb = b.shape[1]
+    out = new_act(N, H, W, 8, dt, a.device)
+    check(lib().tfc_pack_nhwc8(stream_ptr(), dt, _p(a), Ca, _p(b), Cb, out.ptr, N, H, W), "tfc_pack_nhwc8")
+    return out
+
+
+def unpack_nchw(dt, v: View, C, out=None, alpha=1.0, beta=0.0, c0=0):
+    N, H, W = v.N, v.H, v.W
+    if out is None:
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=v.t.device)
+    check(lib().tfc_unpack_nchw(stream_ptr(), dt, v.ptr, v.pitch, c0, C, _p(out), N, H, W, alpha, beta), "tfc_unpack_nchw")
+    return out
+
+
+def tanh_bwd_pack(dt, g, y, dbias=None):
+    N, C, H, W = g.shape
+    out = new_act(N, H, W, 8, dt, g.device)
+    check(lib().tfc_tanh_bwd_pack(stream_ptr(), dt, _p(g), _p(y), out.ptr, _p(dbias), N, C, H, W), "tfc_tanh_bwd_pack")
+    return out
+
+
+def colsum(dt, v: View, out):
+    rows = v.N * v.H * v.W
+    check(lib().tfc_colsum(stream_ptr(), dt, v.ptr, rows, v.pitch, v.C, _p(out)), "tfc_colsum")
+
+
+def cast_from_f32(dt, x):
+    y = torch.empty(x.shape, dtype=torch_dtype(dt), device=x.device)
+    check(lib().tfc_cast(stream_ptr(), dt, 0, _p(x.contiguous()), _p(y), x.numel()), "tfc_cast")
+    return y
+
+
+def cast_to_f32(dt, x):
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().tfc_cast(stream_ptr(), dt, 1, _p(x.contiguous()), _p(y), x.numel()), "tfc_cast")
+    return y
+
+
+def axpby(out, x, y, a, b):
+    check(lib().tfc_axpby(stream_ptr(), _p(out), _p(x), _p(y), out.numel(), a, b), "tfc_axpby")
+    return out
+
+
+# ---- spectral norm --------------------------------------------------------------------------------------------
+def spectral_norm_step(W, u, v, sigma2, power_iter=True, ws=None):
+    R = W.shape[0]
+    K = W.numel() // R
+    if ws is None:
+        ws = torch.empty(R + K, dtype=torch.float32, device=W.device)
+    check(lib().tfc_spectral_norm_step(stream_ptr(), _p(W), _p(u), _p(v), _p(sigma2), _p(ws), R, K, 1 if power_iter else 0),
+          "tfc_spectral_norm_step")
+
+
+def spectral_norm_bwd(G, W, u, v, sigma2, gout, accumulate=False):
+    R = W.shape[0]
+    K = W.numel() // R
+    ws = torch.empty(1, dtype=torch.float32, device=W.device)
+    check(lib().tfc_spectral_norm_bwd(stream_ptr(), _p(G), _p(W), _p(u), _p(v), _p(sigma2), _p(ws), _p(gout), R, K,
+                                      1 if accumulate else 0), "tfc_spectral_norm_bwd")
+
+
+# ---- loss heads -----------------------------------------------------------------------------------------------
+def patch16_triplet(fake, real, neg_idx, want_grad=True, gscale=1.0):
+    """fake/real: fp32 NCHW [N,C,256,256]; neg_idx: 16 ints. Returns (loss[1], dfake or None)."""
+    require_gpu(fake, real)
+    assert fake.shape == real.shape and fake.shape[2:] == (256, 256), "make_16_patches hard-codes 256x256 (reference :233-251)"
+    fake = fake.contiguous().float()
+    real = real.contiguous().float()
+    N, C = fake.shape[:2]
+    loss = torch.empty(1, dtype=torch.float32, device=fake.device)
+    dfake = torch.empty_like(fake) if want_grad else None
+    idx = (ctypes.c_int * 16)(*[int(i) for i in neg_idx])
+    check(lib().tfc_patch16_triplet(stream_ptr(), _p(fake), _p(real), idx, N, C, _p(loss), _p(dfake), gscale), "tfc_patch16_triplet")
+    return loss, dfake
+
+
+def fft_spectrum(img, S, wins_x, wins_y, shift=True):
+    """img: fp32 [N,C,H,W] (any strides on N/C/H, unit stride on W). Returns amp, pha [N*wins_x*wins_y, S, S//2+1]."""
+    require_gpu(img)
+    if img.dtype != torch.float32:
+        img = img.float()
+    if img.stride(3) != 1:
+        img = img.contiguous()
+    N, C = img.shape[:2]
+    assert img.shape[2] >= wins_y * S and img.shape[3] >= wins_x * S
+    nwin = N * wins_x * wins_y
+    amp = torch.empty((nwin, S, S // 2 + 1), dtype=torch.float32, device=img.device)
+    pha = torch.empty_like(amp)
+    check(lib().tfc_fft_spectrum(stream_ptr(), _p(img), img.stride(0), img.stride(1), img.stride(2), C, S, wins_x, wins_y, N,
+                                 _p(amp), _p(pha), 1 if shift else 0), "tfc_fft_spectrum")
+    return amp, pha
+
+
+def l1_sum(a, b, scale, out, zero_first=False):
+    check(lib().tfc_l1_sum(stream_ptr(), _p(a), _p(b), a.numel(), scale, _p(out), 1 if zero_first else 0), "tfc_l1_sum")
+
+
+def bce_relativistic(dt, a: View, b: View, mode, t1, t2=0.0, da: View = None, db: View = None, gscale=1.0):
+    n = a.N * a.H * a.W
+    loss = torch.empty(1, dtype=torch.float32, device=a.t.device)
+    check(lib().tfc_bce_relativistic(stream_ptr(), dt, a.ptr, b.ptr, n, a.pitch, t1, t2, mode, _p(loss),
+                                     None if da is None else da.ptr, None if db is None else db.ptr, gscale), "tfc_bce_relativistic")
+    return loss
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, gscale=1.0):
+    check(lib().tfc_adam_step(stream_ptr(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, gscale), "tfc_adam_step")
+
+
+# ---- measurement ----------------------------------------------------------------------------------------------
+def prof_enable(on):
+    check(lib().tfc_prof_enable(1 if on else 0), "tfc_prof_enable")
+
+
+def prof_collect(kclass):
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+    check(lib().tfc_prof_collect(kclass, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "tfc_prof_collect")
+    return ms.value, fl.value, n.value
