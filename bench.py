@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Benchmark of the PATCH-16 training hot path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; each rank trains on its own 32 synthetic 256x256 thermal/visible pairs already resident in HBM
+(weak scaling), gradients are all-reduced over RCCL.  A "step" = the full generator step + discriminator step of
+TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py:545-638 (without LPIPS / temperature head).  Rank 0 prints ONE
+JSON line.  `roofline` is measured live with hipEvents around every launch of the dominant kernel (tfc_igemm_kernel, the
+halo-staged implicit-GEMM convolution) during the timed region; `cpu_baseline` times the CPU oracle (torch fp32 restatement
+of the same step) on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 32
+MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(sample_n=4):
+    """the oracle's TrainStep on the host cores: one untimed step (allocator / thread-pool warm-up) at N=2, one timed at N=sample_n"""
+    import torch
+    from oracle import tfcgan_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    G = O.GeneratorUNet((3, 256, 256))
+    D = O.Discriminator1((3, 256, 256))
+    G.apply(O.weights_init_normal)
+    D.apply(O.weights_init_normal)
+    ts = O.TrainStep(G, D)
+    neg = list(range(1, 16)) + [0]
+    A, B = O.synthetic_pairs(2, seed=1)
+    ts.step(A, B, neg)
+    A, B = O.synthetic_pairs(sample_n, seed=2)
+    t0 = time.perf_counter()
+    ts.step(A, B, neg)
+    dt = time.perf_counter() - t0
+    return {"value": sample_n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 full PATCH-16 step (G step + D step, triplet16 + patch-FFT) on {sample_n} synthetic 256x256 pairs, torch fp32, "
+                      f"{cores} threads, {dt:.1f} s"}
+
+
+def generator_l1(dev):
+    """generator L1 vs the oracle on one synthetic image, fp32 parity mode and bf16 mode (the 'gen L1 vs ref' half of the metric)"""
+    import torch
+    import tfc_gan_amd as T
+    from oracle import tfcgan_oracle as O
+    A, _ = O.synthetic_pairs(1, seed=11)
+    Gc = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=3).eval()
+    with torch.no_grad():
+        want = Gc(A)
+    out = {}
+    for name, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        T.set_compute_dtype(dtype)
+        G = T.GeneratorUNet((3, 256, 256))
+        G.load_state_dict(Gc.state_dict())
+        G = G.to(dev).eval()
+        with torch.no_grad():
+            got = G(A.to(dev)).cpu()
+        out[name] = float((got - want).abs().mean())
+    T.set_compute_dtype(torch.bfloat16)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (BASELINE config: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import tfc_gan_amd as T
+    from oracle import tfcgan_oracle as O               # synthetic-input recipe only (inputs are data, not the measured path)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    T.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(42)                                # reference: torch.manual_seed(42), P16:61
+    G = T.GeneratorUNet((3, 256, 256)).to(dev)
+    D = T.Discriminator1((3, 256, 256)).to(dev)
+    G.apply(T.weights_init_normal)
+    D.apply(T.weights_init_normal)
+    ts = T.TrainStep(G, D, compute_dtype=torch.bfloat16)
+    A, B = O.synthetic_pairs(args.batch, seed=1234 + rank)
+    A, B = A.to(dev), B.to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(A, B)
+    barrier()
+    T.ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = ts.step(A, B)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    T.ops.prof_enable(False)
+    ig_ms, ig_flop, ig_n = T.ops.prof_collect(0)
+    wg_ms, wg_flop, wg_n = T.ops.prof_collect(1)
+    loss_g, loss_d = float(out["loss_G"]), float(out["loss_D"])
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = args.batch * world * args.steps / elapsed
+        achieved = (ig_flop / 1e12) / (ig_ms / 1e3) if ig_ms > 0 else 0.0
+        line = {
+            "metric": "training images/sec at 256x256 PATCH-16, 1/2/4/8 MI355X; gen L1 vs ref",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "PATCH-16 256x256 bf16, batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
+                                   "G step + D step, 16-patch triplet + patch-FFT loss, Adam",
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_image": T.TrainStep.STEP_GFLOP},
+            "roofline": {"bound": "mfma", "kernel": "tfc_igemm_kernel (halo-staged implicit-GEMM conv: fwd/dgrad/convT/upconv)",
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": None, "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
+                         "share_of_step_time": (ig_ms / 1e3) / elapsed,
+                         "second_kernel": {"kernel": "tfc_wgrad_kernel", "achieved": (wg_flop / 1e12) / (wg_ms / 1e3) if wg_ms > 0 else 0.0,
+                                           "unit": "TFLOP/s", "launches": wg_n, "share_of_step_time": (wg_ms / 1e3) / elapsed}},
+            "whole_step_tflops": T.TrainStep.STEP_GFLOP * value / 1e3,
+            "final_losses": {"loss_G": loss_g, "loss_D": loss_d},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["generator_l1_vs_oracle"] = generator_l1(dev)
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

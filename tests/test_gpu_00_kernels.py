@@ -1,0 +1,323 @@
+"""GPU parity tests, kernel level: every HIP entry point of include/tfc_gan.h against the CPU oracle / torch-CPU fp32 on the
+same seeded inputs.  fp32 mode (TFC_DT_F32) must agree to fp32 round-off; bf16 mode is compared against the same
+computation done on bf16-rounded operands, with a tolerance of a few bf16 ulps of the result scale (stated per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import tfc_gan_amd as T
+from oracle import tfcgan_oracle as O
+from tfc_gan_amd import _lib, ops
+from tfc_gan_amd.ops import DT_BF16, DT_F32, View
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def q(x, dt):
+    """round to the storage dtype (identity in fp32 mode)"""
+    return x.to(torch.bfloat16).float() if dt == DT_BF16 else x
+
+
+def to_view(x_nchw, dt, pad_to=None):
+    """NCHW fp32 CPU -> NHWC View on the GPU in dtype dt (channels zero-padded to a multiple of 8)."""
+    n, c, h, w = x_nchw.shape
+    cp = pad_to or ops.pad8(c)
+    t = torch.zeros((n, h, w, cp), dtype=torch.float32)
+    t[..., :c] = x_nchw.permute(0, 2, 3, 1)
+    return View(t.to(DEV).to(ops.torch_dtype(dt)).contiguous(), c)
+
+
+def from_view(v, c=None):
+    c = c or v.C
+    return v.t[..., v.coff:v.coff + c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def tol(dt, scale):
+    return (2e-5 if dt == DT_F32 else 1.2e-2) * max(scale, 1e-6)
+
+
+def test_probe_lane_maps():
+    """the MFMA / transposing-read lane maps every kernel is written against (integer data, exact)"""
+    out = torch.zeros(2560, dtype=torch.float32, device=DEV)
+    _lib.check(_lib.load().tfc_probe_mfma(ops.stream_ptr(), ops._p(out)), "probe")
+    o = out.cpu().numpy()
+    i = np.arange(32)[:, None]
+    j = np.arange(32)[None, :]
+    for sec, K in ((0, 16), (1, 2)):
+        k = np.arange(K)
+        A = (3 * i[:, :, None] + k[None, None, :]) % 7          # A[i][k]
+        B = (k[:, None] + 5 * j[0][None, :]) % 5                # B[k][j]
+        D = (A[:, 0, :].astype(np.float64) @ B.astype(np.float64))
+        got = np.zeros((32, 32))
+        for l in range(64):
+            for r in range(16):
+                got[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = o[sec * 1024 + l * 16 + r]
+        np.testing.assert_array_equal(got, D)
+    for l in range(64):
+        for e in range(8):
+            assert o[2048 + l * 8 + e] == (8 * (l >> 5) + e) * 32 + 16 * ((l >> 4) & 1) + (l & 15)
+
+
+def ref_conv(op, x, w, bias=None):
+    if op == ops.OP_CONV:
+        return F.conv2d(x, w, bias, padding=1)
+    if op == ops.OP_PADCONV:
+        return F.conv2d(F.pad(x, (1, 0, 1, 0)), w, bias, padding=1)
+    if op == ops.OP_CONVT:
+        return F.conv_transpose2d(x, w, bias, stride=2, padding=1)
+    return F.conv2d(F.pad(F.interpolate(x, scale_factor=2), (1, 0, 1, 0)), w, bias, padding=1)
+
+
+CONV_CASES = [  # op, N, H, W, Cin, Cout
+    (ops.OP_CONV, 2, 20, 20, 64, 128), (ops.OP_CONV, 1, 33, 18, 3, 64), (ops.OP_CONV, 2, 9, 9, 128, 64),
+    (ops.OP_CONV, 1, 16, 16, 6, 64), (ops.OP_CONV, 1, 8, 8, 512, 512), (ops.OP_PADCONV, 2, 16, 16, 512, 1),
+    (ops.OP_CONVT, 2, 4, 4, 512, 512), (ops.OP_CONVT, 1, 17, 9, 256, 64), (ops.OP_CONVT, 1, 8, 8, 1024, 256),
+    (ops.OP_UPCONV, 1, 16, 24, 128, 3),
+]
+
+
+@pytest.mark.parametrize("dt", [DT_F32, DT_BF16])
+@pytest.mark.parametrize("op,N,H,W,Cin,Cout", CONV_CASES)
+def test_conv_family(op, N, H, W, Cin, Cout, dt):
+    seed = op * 1000 + Cin + Cout
+    K = Cin * (4 if op == ops.OP_CONVT else 16)
+    x = q(rnd((N, Cin, H, W), seed), dt).requires_grad_(True)
+    wshape = (Cin, Cout, 4, 4) if op == ops.OP_CONVT else (Cout, Cin, 4, 4)
+    w = rnd(wshape, seed + 1, 1.0 / np.sqrt(K))
+    wq = q(w, dt).requires_grad_(True)
+    bias = rnd((Cout,), seed + 2, 0.5)
+    y = ref_conv(op, x, wq, bias)
+    go = q(rnd(tuple(y.shape), seed + 3), dt)
+    gx, gw = torch.autograd.grad(y, (x, wq), go)
+    OH, OW = y.shape[2:]
+    wd = w.to(DEV)
+    xv = to_view(x.detach(), dt)
+    # forward (+ bias, + InstanceNorm statistics epilogue)
+    yv = ops.new_act(N, OH, OW, ops.pad8(Cout), dt, DEV, zero=True)
+    stats = torch.zeros((N, Cout, 2), dtype=torch.float32, device=DEV)
+    pk = ops.pack_weight(dt, op, 0, wd, Cin, Cout)
+    ops.conv_fwd(dt, op, xv, Cin, Cout, pk, View(yv.t, Cout), bias=bias.to(DEV), stats=stats)
+    got = from_view(View(yv.t, Cout))
+    assert (got - y.detach()).abs().max().item() <= tol(dt, y.abs().max().item())
+    s1 = y.detach().sum((2, 3))
+    s2 = (y.detach() ** 2).sum((2, 3))
+    # the statistics are taken from the fp32 accumulators (before the store rounds to bf16)
+    assert torch.allclose(stats[..., 0].cpu(), s1, rtol=2e-3, atol=2e-4 * OH * OW)
+    assert torch.allclose(stats[..., 1].cpu(), s2, rtol=2e-3, atol=2e-4 * OH * OW)
+    # dgrad (+ accumulate)
+    gov = to_view(go, dt)
+    dxv = ops.new_act(N, H, W, ops.pad8(Cin), dt, DEV, zero=True)
+    pkd = ops.pack_weight(dt, op, 1, wd, Cin, Cout)
+    ops.conv_dgrad(dt, op, gov, N, H, W, Cin, Cout, pkd, View(dxv.t, Cin))
+    got = from_view(View(dxv.t, Cin))
+    assert (got - gx).abs().max().item() <= tol(dt, gx.abs().max().item())
+    ops.conv_dgrad(dt, op, gov, N, H, W, Cin, Cout, pkd, View(dxv.t, Cin), accumulate=True)
+    got2 = from_view(View(dxv.t, Cin))
+    assert (got2 - 2 * gx).abs().max().item() <= 2.5 * tol(dt, gx.abs().max().item())
+    # wgrad (+ accumulate)
+    dw = torch.zeros(wshape, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(dt, op, xv, gov, Cin, Cout, dw)
+    wtol = (1e-4 if dt == DT_F32 else 2e-3) * gw.abs().max().item() + 1e-5
+    assert (dw.cpu() - gw).abs().max().item() <= wtol
+    ops.conv_wgrad(dt, op, xv, gov, Cin, Cout, dw, accumulate=True)
+    assert (dw.cpu() - 2 * gw).abs().max().item() <= 2 * wtol
+
+
+def test_upconv_tanh_nchw_head():
+    """generator head: Upsample + ZeroPad + Conv + Tanh written as fp32 NCHW (P16:153-158)"""
+    for dt in (DT_F32, DT_BF16):
+        x = q(rnd((2, 128, 16, 16), 5), dt)
+        w = rnd((3, 128, 4, 4), 6, 0.02)
+        b = rnd((3,), 7, 0.1)
+        want = torch.tanh(ref_conv(ops.OP_UPCONV, x, q(w, dt), b))
+        out = torch.empty((2, 3, 32, 32), dtype=torch.float32, device=DEV)
+        ops.conv_fwd(dt, ops.OP_UPCONV, to_view(x, dt), 128, 3, ops.pack_weight(dt, ops.OP_UPCONV, 0, w.to(DEV), 128, 3), None,
+                     bias=b.to(DEV), out_nchw=out)
+        assert (out.cpu() - want).abs().max().item() <= (1e-5 if dt == DT_F32 else 4e-3)
+
+
+def oracle_act(x, norm, slope, pool, mask=None, drop_p=0.0):
+    y = F.instance_norm(x, eps=1e-5) if norm else x
+    y = torch.where(y > 0, y, y * slope)
+    if pool:
+        y = O.BlurPool(x.shape[1], stride=pool)(y)
+    if mask is not None:
+        y = y * mask / (1.0 - drop_p)
+    return y
+
+
+ACT_CASES = [  # C, H, W, norm, slope, pool, drop
+    (64, 15, 15, True, 0.2, 2, 0.0), (128, 7, 7, True, 0.2, 2, 0.5), (64, 31, 30, False, 0.2, 2, 0.0), (512, 8, 8, True, 0.0, 0, 0.5),
+    (64, 14, 14, False, 1.0, 1, 0.0), (256, 3, 3, True, 0.2, 2, 0.0), (8, 9, 9, False, 0.2, 2, 0.0),
+]
+
+
+@pytest.mark.parametrize("dt", [DT_F32, DT_BF16])
+@pytest.mark.parametrize("C,H,W,norm,slope,pool,drop", ACT_CASES)
+def test_fused_act_fwd_bwd(C, H, W, norm, slope, pool, drop, dt):
+    N, seed = 2, 77
+    x = q(rnd((N, C, H, W), C + H) * 1.5 + 0.3, dt).requires_grad_(True)
+    Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if pool == 2 else (H, W)
+    mask = None
+    if drop:
+        keep = O.hip_keep_mask(seed, N * Ho * Wo * C, drop).reshape(N, Ho, Wo, C)
+        mask = torch.from_numpy(np.ascontiguousarray(keep.transpose(0, 3, 1, 2))).float()
+        dev_mask = ops.dropout_mask(N * Ho * Wo * C, drop, seed, DEV).cpu().numpy().astype(bool)
+        np.testing.assert_array_equal(dev_mask, keep.reshape(-1))          # kernel RNG == numpy restatement
+    y = oracle_act(x, norm, slope, pool, mask, drop)
+    go = q(rnd(tuple(y.shape), 3), dt)
+    (gx,) = torch.autograd.grad(y, x, go)
+    xv = to_view(x.detach(), dt)
+    stats = None
+    if norm:
+        xs = xv.t.float()
+        stats = torch.stack((xs.sum((1, 2)), (xs * xs).sum((1, 2))), -1).contiguous()      # [N,C,2]
+    yv = ops.new_act(N, Ho, Wo, C, dt, DEV)
+    so = torch.zeros((N, C, 2), dtype=torch.float32, device=DEV)
+    ops.act_fwd(dt, xv, yv, stats=stats, slope=slope, pool=pool, drop_p=drop, seed=seed, stats_out=so)
+    got = from_view(yv)
+    t = 2e-5 if dt == DT_F32 else 2e-2
+    assert (got - y.detach()).abs().max().item() <= t * max(1.0, y.abs().max().item())
+    assert torch.allclose(so[..., 0].cpu(), y.detach().sum((2, 3)), rtol=2e-3, atol=(2e-2 if dt == DT_BF16 else 2e-4) * Ho * Wo)
+    assert torch.allclose(so[..., 1].cpu(), (y.detach() ** 2).sum((2, 3)), rtol=2e-2 if dt == DT_BF16 else 2e-3, atol=1e-3 * Ho * Wo)
+    gov = to_view(go, dt)
+    dxv = ops.new_act(N, H, W, C, dt, DEV)
+    if norm:
+        rstats = torch.zeros((N, C, 2), dtype=torch.float32, device=DEV)
+        ops.act_bwd(dt, 1, gov, xv, N, H, W, C, None, stats=stats, slope=slope, pool=pool, drop_p=drop, seed=seed, rstats=rstats)
+        ops.act_bwd(dt, 2, gov, xv, N, H, W, C, dxv, stats=stats, slope=slope, pool=pool, drop_p=drop, seed=seed, rstats=rstats)
+    else:
+        ops.act_bwd(dt, 0, gov, xv if slope != 1.0 else None, N, H, W, C, dxv, stats=None, slope=slope, pool=pool, drop_p=drop, seed=seed)
+    gotg = from_view(dxv)
+    assert (gotg - gx).abs().max().item() <= (5e-5 if dt == DT_F32 else 3e-2) * max(1.0, gx.abs().max().item())
+
+
+def test_pack_unpack_tanh_colsum():
+    for dt in (DT_F32, DT_BF16):
+        a, b = rnd((2, 3, 16, 24), 1), rnd((2, 3, 16, 24), 2)
+        v = ops.pack_nhwc8(dt, a.to(DEV), b.to(DEV))
+        want = torch.cat((a, b, torch.zeros(2, 2, 16, 24)), 1)
+        assert torch.allclose(from_view(v), q(want, dt), atol=0)
+        back = ops.unpack_nchw(dt, v, 3, c0=3)
+        assert torch.allclose(back.cpu(), q(b, dt), atol=0)
+        acc = ops.unpack_nchw(dt, v, 3, out=back.clone(), alpha=2.0, beta=1.0, c0=0)
+        assert torch.allclose(acc.cpu(), q(b, dt) + 2 * q(a, dt), atol=1e-6)
+        g, y = rnd((2, 3, 16, 24), 3), torch.tanh(rnd((2, 3, 16, 24), 4))
+        db = torch.zeros(3, dtype=torch.float32, device=DEV)
+        dv = ops.tanh_bwd_pack(dt, g.to(DEV), y.to(DEV), dbias=db)
+        want = g * (1 - y * y)
+        assert (from_view(dv, 3) - want).abs().max().item() <= (1e-6 if dt == DT_F32 else 2e-2)
+        assert torch.allclose(db.cpu(), want.sum((0, 2, 3)), atol=1e-3)
+        assert from_view(dv, 8)[:, 3:].abs().max().item() == 0
+        x = q(rnd((2, 64, 9, 11), 5), dt)
+        cs = torch.zeros(64, dtype=torch.float32, device=DEV)
+        ops.colsum(dt, to_view(x, dt), cs)
+        assert torch.allclose(cs.cpu(), x.sum((0, 2, 3)), atol=1e-3, rtol=1e-4)
+
+
+def test_spectral_norm_step_and_backward():
+    R, K = 128, 1024
+    W = rnd((R, K), 1, 0.05)
+    u = F.normalize(rnd((R,), 2), dim=0)
+    v = F.normalize(rnd((K,), 3), dim=0)
+    Wd, ud, vd = W.to(DEV), u.to(DEV), v.to(DEV)
+    s2 = torch.zeros(2, dtype=torch.float32, device=DEV)
+    uu, vv = u, v
+    for it in range(3):
+        ops.spectral_norm_step(Wd, ud, vd, s2, power_iter=True)
+        uu, vv, sigma = O.spectral_norm_step(W, uu, vv)
+        assert torch.allclose(ud.cpu(), uu, atol=2e-6) and torch.allclose(vd.cpu(), vv, atol=2e-6)
+        assert abs(s2[0].item() - sigma.item()) < 1e-5 * sigma.item() and abs(s2[1].item() * sigma.item() - 1) < 1e-5
+    ops.spectral_norm_step(Wd, ud, vd, s2, power_iter=False)              # eval mode: sigma only
+    assert torch.allclose(ud.cpu(), uu, atol=2e-6) and abs(s2[0].item() - sigma.item()) < 1e-5 * sigma.item()
+    Wr = W.clone().requires_grad_(True)
+    sig = torch.dot(uu, Wr @ vv)
+    G = rnd((R, K), 9)
+    ((Wr / sig) * G).sum().backward()
+    gout = torch.zeros((R, K), dtype=torch.float32, device=DEV)
+    ops.spectral_norm_bwd(G.to(DEV), Wd, ud, vd, s2, gout)
+    assert (gout.cpu() - Wr.grad).abs().max().item() <= 1e-4 * Wr.grad.abs().max().item()
+
+
+def test_triplet16_vs_oracle_and_golden(golden):
+    g = golden("triplet16")
+    fk, rl = O.synthetic_pairs(2, seed=31)
+    fk = torch.tanh(fk * 1.5).requires_grad_(True)
+    neg = g["neg_idx"].tolist()
+    want = O.patch_triplet_loss(fk, rl, neg)
+    want.backward()
+    loss, dfake = ops.patch16_triplet(fk.detach().to(DEV), rl.to(DEV), neg)
+    assert abs(loss.item() - float(g["loss"])) < 2e-6 and abs(loss.item() - want.item()) < 2e-6
+    assert (dfake.cpu() - fk.grad).abs().max().item() < 1e-9 + 1e-5 * fk.grad.abs().max().item()
+    assert torch.allclose(dfake.cpu()[:, :, ::4, ::4], torch.from_numpy(g["gfake_sub"]), atol=1e-9, rtol=1e-4)
+    # r_k == k for every k: each hinge is exactly the margin and the gradient vanishes
+    l1, d1 = ops.patch16_triplet(fk.detach().to(DEV), rl.to(DEV), list(range(16)))
+    assert abs(l1.item() - 1.0) < 1e-6 and d1.abs().max().item() == 0.0
+    # autograd surface
+    f2 = fk.detach().to(DEV).requires_grad_(True)
+    T.ContrastiveLoss()(f2, rl.to(DEV), neg).backward()
+    assert torch.allclose(f2.grad.cpu(), fk.grad, atol=1e-9, rtol=1e-4)
+
+
+def test_fft_spectrum_vs_oracle_and_golden(golden):
+    gp, gg = golden("fft_patch"), golden("fft_global")
+    ff, rr = O.synthetic_pairs(1, seed=41)
+    ff = torch.tanh(ff * 2.0) * 0.999
+    amp, pha = T.fft_components(T.make_16_patches(ff.to(DEV))[5])
+    a_ref, p_ref = torch.from_numpy(gp["amp5"]), torch.from_numpy(gp["pha5"])
+    assert amp.shape == (1, 1, 64, 33)
+    assert (amp.cpu() - a_ref).abs().max().item() <= 2e-6 * a_ref.max().item() + 2e-2         # fp32 DFT of 8-bit data
+    dphi = (pha.cpu() - p_ref).abs()
+    dphi = torch.minimum(dphi, 2 * np.pi - dphi)                                              # +-pi are the same angle
+    assert (dphi * a_ref).max().item() <= 0.05                                                # |dphi| <= 0.05 / amplitude
+    loss, la, lp = T.patch_fft_loss(ff.to(DEV), rr.to(DEV))
+    want, wa, wp = O.patch_fft_loss(ff, rr)
+    assert abs(loss.item() - float(gp["loss_fft"])) <= 2e-4 * float(gp["loss_fft"])
+    assert abs(la.item() - wa.item()) <= 1e-4 * wa.item() and abs(lp.item() - wp.item()) <= 2e-3
+    assert abs(T.calculate_ffts(*T.make_16_patches(ff.to(DEV)), *T.make_16_patches(rr.to(DEV))).item() - want.item()) <= 2e-4 * want.item()
+    # GLO-16: 256 x 129
+    ga, gph = T.fft_components(ff.to(DEV), patch=False)
+    assert ga.shape == (1, 1, 256, 129)
+    ar = torch.from_numpy(gg["amp_sub"])
+    assert (ga.cpu()[:, :, ::4, ::3] - ar).abs().max().item() <= 2e-6 * ar.max().item() + 0.2
+    gl, _, _ = T.global_fft_loss(ff.to(DEV), rr.to(DEV))
+    assert abs(gl.item() - float(gg["loss_fft"])) <= 3e-4 * float(gg["loss_fft"])
+    # identical images -> exactly zero loss
+    z, _, _ = T.patch_fft_loss(ff.to(DEV), ff.to(DEV))
+    assert z.item() == 0.0
+
+
+def test_bce_relativistic_golden(golden):
+    g = golden("bce_relativistic")
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    for dt in (DT_F32,):
+        av, bv = to_view(a, dt), to_view(b, dt)
+        da = ops.new_act(2, 16, 16, 8, dt, DEV, zero=True)
+        db = ops.new_act(2, 16, 16, 8, dt, DEV, zero=True)
+        lg = ops.bce_relativistic(dt, View(av.t, 1), View(bv.t, 1), 0, 0.9, da=View(da.t, 1))
+        assert abs(lg.item() - float(g["loss_g"])) < 1e-6
+        ar = a.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        O.loss_gan_generator(ar, b).backward()
+        assert torch.allclose(from_view(View(da.t, 1)), ar.grad, atol=1e-8)
+        ld = ops.bce_relativistic(dt, View(av.t, 1), View(bv.t, 1), 1, 0.9, 0.0, da=View(da.t, 1), db=View(db.t, 1))
+        assert abs(ld.item() - float(g["loss_d"])) < 1e-6
+        ar.grad = None
+        O.loss_discriminator(ar, br).backward()
+        assert torch.allclose(from_view(View(da.t, 1)), ar.grad, atol=1e-8) and torch.allclose(from_view(View(db.t, 1)), br.grad, atol=1e-8)
+
+
+def test_adam_vs_oracle():
+    p, m, v = rnd((1000,), 1), torch.zeros(1000), torch.zeros(1000)
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    for step in (1, 2, 3):
+        g = rnd((1000,), 10 + step)
+        ops.adam_step(pd, g.to(DEV), md, vd, 2e-4, 0.5, 0.999, 1e-8, step)
+        p, m, v = O.adam_step(p, g, m, v, step)
+        assert torch.allclose(pd.cpu(), p, atol=1e-7) and torch.allclose(md.cpu(), m, atol=1e-7)

@@ -1,0 +1,197 @@
+"""GPU parity tests, network level: the nn.Module mirrors (reference call surface) and the fused TrainStep against the CPU
+oracle and against the fixtures generated from the reference's own definitions (tests/golden).
+
+fp32 parity mode: generator L1 vs oracle <= 1e-4 (BASELINE.json north_star), typically ~1e-6.
+bf16 mode       : stated per test (bf16 keeps 8 significant bits; 12 layers of InstanceNorm-separated convolutions)."""
+import numpy as np
+import pytest
+import torch
+
+import tfc_gan_amd as T
+from oracle import tfcgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(autouse=True)
+def _fp32_default():
+    T.set_compute_dtype(torch.float32)
+    yield
+    T.set_compute_dtype(torch.bfloat16)
+
+
+def test_blocks_vs_reference_goldens(golden):
+    rng = np.random.default_rng(7)
+    rn = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))  # noqa: E731
+    cases = [("block_down_norm", T.UNetDown(8, 16), [rn(2, 8, 16, 16)], 21),
+             ("block_down_nonorm", T.UNetDown(8, 16, normalize=False), [rn(2, 8, 15, 15)], 22),
+             ("block_up", T.UNetUp(16, 8), [rn(2, 16, 7, 7), rn(2, 8, 14, 14)], 23)]
+    for tag, mod, xs, seed in cases:
+        g = golden(tag)
+        O.init_weights_portable(mod, seed)
+        mod = mod.to(DEV).eval()
+        xs = [x.to(DEV).requires_grad_(True) for x in xs]
+        y = mod(*xs)
+        y.backward(t(g["go"]).to(DEV))
+        w = next(mod.parameters())
+        assert (y.cpu() - t(g["y"])).abs().max().item() < 2e-5, tag
+        assert (xs[0].grad.cpu() - t(g["gx"])).abs().max().item() < 5e-5, tag
+        assert (w.grad.cpu() - t(g["gw"])).abs().max().item() < 2e-4, tag
+
+
+def test_generator_l1_vs_golden_fp32(golden):
+    g = golden("generator_fwd")
+    A, _ = O.synthetic_pairs(1, seed=11)
+    G = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=3).to(DEV).eval()
+    with torch.no_grad():
+        fake = G(A.to(DEV)).cpu()
+    assert fake.shape == (1, 3, 256, 256) and fake.dtype == torch.float32
+    l1 = (fake[:, :, ::8, ::8] - t(g["fake_sub"])).abs().mean().item()
+    assert l1 <= 1e-4, l1                                                  # north_star: generator L1 vs reference <= 1e-4
+    assert (fake[0, :, 0, :] - t(g["fake_row0"])).abs().max().item() <= 5e-5
+    assert abs(fake.abs().mean().item() - float(g["fake_absmean"])) <= 1e-5
+
+
+def test_discriminator_logits_vs_golden_fp32(golden):
+    gg, gd = golden("generator_fwd"), golden("discriminator_fwd")
+    A, _ = O.synthetic_pairs(1, seed=11)
+    Gc = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=3).eval()
+    with torch.no_grad():
+        fake = Gc(A)
+    D = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=4).to(DEV).eval()
+    with torch.no_grad():
+        logits = D(fake.to(DEV), A.to(DEV)).cpu()
+    assert logits.shape == (1, 1, 16, 16)
+    assert (logits - t(gd["logits"])).abs().max().item() <= 2e-4
+
+
+def test_generator_bf16_vs_oracle():
+    """bf16 mode: generator output (tanh range) within 2e-2 mean abs of the fp32 oracle on the same weights / inputs"""
+    T.set_compute_dtype(torch.bfloat16)
+    A, _ = O.synthetic_pairs(2, seed=12)
+    Gc = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=3).eval()
+    with torch.no_grad():
+        want = Gc(A)
+    G = T.GeneratorUNet((3, 256, 256))
+    G.load_state_dict(Gc.state_dict())
+    G = G.to(DEV).eval()
+    with torch.no_grad():
+        got = G(A.to(DEV)).cpu()
+    l1 = (got - want).abs().mean().item()
+    rel = l1 / want.abs().mean().item()
+    print(f"bf16 generator L1 {l1:.3e} (relative {rel:.3e})")
+    assert rel <= 5e-2, (l1, rel)
+
+
+def _train_step_compare(golden, dtype, tol_loss, tol_grad):
+    g = golden("train_step")
+    T.set_compute_dtype(dtype)
+    G = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=61).to(DEV).eval()     # eval: dropout off (as in the golden)
+    D = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=62).to(DEV).train()
+    gb = {k: v.clone() for k, v in G.state_dict().items()}
+    db = {k: v.clone() for k, v in D.state_dict().items()}
+    A, B = O.synthetic_pairs(1, seed=63)
+    ts = T.TrainStep(G, D, compute_dtype=dtype)
+    out = ts.step(A.to(DEV), B.to(DEV), neg_idx=g["neg_idx"].tolist())
+    torch.cuda.synchronize()
+    for k in ("loss_G", "loss_GAN_g", "loss_triplet_patch", "loss_FFT", "loss_D"):
+        want = float(g[k])
+        assert abs(float(out[k]) - want) <= tol_loss * max(1.0, abs(want)), (k, float(out[k]), want)
+    assert (out["fake_B"].cpu()[:, :, ::8, ::8] - t(g["fake_sub"])).abs().mean().item() <= (1e-4 if dtype == torch.float32 else 3e-2)
+
+    def close(got, want, tol):
+        want = t(want)
+        return (got.cpu() - want).abs().max().item() <= tol * want.abs().max().item() + 1e-9
+
+    # gradients left in the flat buffers by the step (sum over the single rank)
+    assert close(ts.gflat.grad_views["down1.model.0.weight"], g["g_grad_down1"], tol_grad)
+    assert close(ts.gflat.grad_views["up3.model.0.weight"][::16, ::16], g["g_grad_up3"], tol_grad)
+    assert close(ts.dflat.grad_views["model.13.weight"], g["d_grad_head"], tol_grad)
+    assert close(ts.dflat.grad_views["model.0.bias"], g["d_grad_b0"], tol_grad)
+    assert close(ts.dflat.grad_views["model.3.parametrizations.weight.original"][::8, ::8], g["d_grad_w3"], tol_grad)
+    if dtype == torch.float32:
+        # Adam deltas: |delta| ~ lr; sign flips of ~zero gradients are excluded by comparing where the reference moved clearly
+        for key, ref in (("final.2.weight", g["g_delta_final_w"]), ("down1.model.0.weight", g["g_delta_down1"])):
+            got = (G.state_dict()[key] - gb[key]).cpu()
+            assert (got - t(ref)).abs().mean().item() <= 2e-6, key
+        got = (D.state_dict()["model.13.weight"] - db["model.13.weight"]).cpu()
+        assert (got - t(g["d_delta_head"])).abs().mean().item() <= 2e-6
+        assert torch.allclose(D.state_dict()["model.3.parametrizations.weight.0._u"].cpu(), t(g["d_u3"]), atol=1e-4)
+
+
+def test_train_step_fp32_vs_reference_golden(golden):
+    _train_step_compare(golden, torch.float32, 2e-4, 2e-3)
+
+
+def test_train_step_bf16_vs_reference_golden(golden):
+    _train_step_compare(golden, torch.bfloat16, 3e-2, 0.15)
+
+
+def test_dropout_train_mode_matches_oracle_with_shared_masks():
+    """training-mode generator (dropout p=0.5 in down3/down4/up2/up3): the oracle consumes the very masks the kernels draw"""
+    A, _ = O.synthetic_pairs(1, seed=21)
+    Gc = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=8).train()
+    core = T.nets.GeneratorCore(T.ops.DT_F32)
+    core.set_params({k: v.to(DEV) for k, v in Gc.state_dict().items() if k in T.nets.g_param_names()})
+    seed = 4242
+    fake, _ = core.forward(A.to(DEV), seed=seed, train=True, save=False)
+    Gc.set_mask_fn(O.hip_mask_fn(seed))
+    with torch.no_grad():
+        want = Gc(A)
+    assert (fake.cpu() - want).abs().mean().item() <= 1e-4
+
+
+def test_full_size_properties_batch32():
+    """BASELINE config (batch 32, 256x256, bf16): size-independent properties instead of a (minutes-long) CPU oracle run"""
+    T.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    N = 32
+    A, B = O.synthetic_pairs(N, seed=99)
+    A, B = A.to(DEV), B.to(DEV)
+    G = T.GeneratorUNet((3, 256, 256)).to(DEV)
+    D = T.Discriminator1((3, 256, 256)).to(DEV)
+    G.apply(T.weights_init_normal)
+    D.apply(T.weights_init_normal)
+    ts = T.TrainStep(G, D)
+    out = ts.step(A, B)
+    torch.cuda.synchronize()
+    fake = out["fake_B"]
+    assert fake.shape == (N, 3, 256, 256) and torch.isfinite(fake).all() and fake.abs().max().item() <= 1.0
+    for k, v in out.items():
+        if k != "fake_B":
+            assert np.isfinite(float(v)), k
+    # per-sample independence (InstanceNorm, per-sample losses): sample 5 alone == sample 5 inside the batch (eval: no dropout)
+    G.eval()
+    with torch.no_grad():
+        full = G(A)
+        one = G(A[5:6])
+    assert (full[5:6] - one).abs().max().item() <= 1e-6
+    # adjoint identity  <conv(x), g> == <x, dgrad(g)> == <w, wgrad(x, g)>  at the size of down2 (64 -> 128 @ 128x128, batch 32)
+    ops = T.ops
+    dt = ops.DT_BF16
+    x = ops.new_act(N, 128, 128, 64, dt, DEV)
+    x.t.copy_(torch.randn(x.t.shape, device=DEV))
+    go = ops.new_act(N, 127, 127, 128, dt, DEV)
+    go.t.copy_(torch.randn(go.t.shape, device=DEV))
+    w = (torch.randn(128, 64, 4, 4, device=DEV) * 0.03).to(torch.bfloat16).float()
+    y = ops.new_act(N, 127, 127, 128, dt, DEV)
+    ops.conv_fwd(dt, ops.OP_CONV, x, 64, 128, ops.pack_weight(dt, ops.OP_CONV, 0, w, 64, 128), y)
+    dx = ops.new_act(N, 128, 128, 64, dt, DEV)
+    ops.conv_dgrad(dt, ops.OP_CONV, go, N, 128, 128, 64, 128, ops.pack_weight(dt, ops.OP_CONV, 1, w, 64, 128), dx)
+    dw = torch.empty_like(w)
+    ops.conv_wgrad(dt, ops.OP_CONV, x, go, 64, 128, dw)
+    a = (y.t.double() * go.t.double()).sum().item()
+    b = (x.t.double() * dx.t.double()).sum().item()
+    c = (w.double() * dw.double()).sum().item()
+    scale = (y.t.double().pow(2).sum().sqrt() * go.t.double().pow(2).sum().sqrt()).item()
+    assert abs(a - b) <= 2e-3 * scale and abs(a - c) <= 2e-3 * scale, (a, b, c, scale)
+    # triplet with r_k = k: exactly the margin; FFT loss of identical images: exactly 0
+    l, d = ops.patch16_triplet(fake, B, list(range(16)))
+    assert abs(l.item() - 1.0) < 1e-6 and d.abs().max().item() == 0.0
+    z, _, _ = T.patch_fft_loss(fake, fake)
+    assert z.item() == 0.0

@@ -162,6 +162,12 @@ hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int
   } else if (S == 256) {
     constexpr int KG = 16;
     const size_t lds = 256 * 256 + 2 * 256 * 4 + 256 * KG * 2 * 4;
+    static bool attr_set = false;                                 // > 64 KiB of dynamic LDS needs an explicit opt-in (once)
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tfc_spectrum_kernel<256, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
     hipLaunchKernelGGL((tfc_spectrum_kernel<256, KG>), dim3(nwin, (129 + KG - 1) / KG), dim3(256), lds, st, img, bs, cs, rs, C, wins_x, wins_per_img, amp, pha, shift);
   } else {
     return hipErrorInvalidValue;
