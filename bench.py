@@ -24,11 +24,12 @@ PER_GPU_BATCH = 32
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(sample_n=4):
-    """the oracle's TrainStep on the host cores: one untimed step (allocator / thread-pool warm-up) at N=2, one timed at N=sample_n"""
+def cpu_baseline(sample_n=2):
+    """the oracle's TrainStep on the host cores: one untimed step (allocator / thread-pool warm-up) at N=1, one timed at N=sample_n.
+    Threads: the box's CPU share for one GPU is 16 cores (more torch threads than that only oversubscribe)."""
     import torch
     from oracle import tfcgan_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     G = O.GeneratorUNet((3, 256, 256))
     D = O.Discriminator1((3, 256, 256))
@@ -36,7 +37,7 @@ def cpu_baseline(sample_n=4):
     D.apply(O.weights_init_normal)
     ts = O.TrainStep(G, D)
     neg = list(range(1, 16)) + [0]
-    A, B = O.synthetic_pairs(2, seed=1)
+    A, B = O.synthetic_pairs(1, seed=1)
     ts.step(A, B, neg)
     A, B = O.synthetic_pairs(sample_n, seed=2)
     t0 = time.perf_counter()

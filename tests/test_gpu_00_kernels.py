@@ -195,7 +195,17 @@ def test_fused_act_fwd_bwd(C, H, W, norm, slope, pool, drop, dt):
     else:
         ops.act_bwd(dt, 0, gov, xv if slope != 1.0 else None, N, H, W, C, dxv, stats=None, slope=slope, pool=pool, drop_p=drop, seed=seed)
     gotg = from_view(dxv)
-    assert (gotg - gx).abs().max().item() <= (5e-5 if dt == DT_F32 else 3e-2) * max(1.0, gx.abs().max().item())
+    err = (gotg - gx).abs()
+    if slope != 1.0:
+        # LeakyReLU'(0) is a knife edge: an element with xhat ~ 0 (bf16-quantised planes hit it exactly) may take either slope,
+        # and through the InstanceNorm backward that changes its whole plane -- exclude such planes from the comparison
+        if norm:
+            bad = (F.instance_norm(x.detach(), eps=1e-5).abs() < 1e-3).flatten(2).any(-1)[:, :, None, None]
+        else:
+            bad = x.detach().abs() < 1e-3
+        err = err * (~bad)
+        assert bad.float().mean().item() < 0.5
+    assert err.max().item() <= (5e-5 if dt == DT_F32 else 3e-2) * max(1.0, gx.abs().max().item())
 
 
 def test_pack_unpack_tanh_colsum():

@@ -79,3 +79,21 @@ __device__ __forceinline__ int tfc_xcd_remap(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, w = bid >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + w;
 }
+
+// Scalar reduction across workgroups without fp32 atomic round-off: every workgroup adds its partial as a DOUBLE atomic
+// (memory-side, device scope) and takes an arrival ticket; the last arriver reads the total, adds it to out[0] and re-arms
+// the slot.  One thread per workgroup calls this.  Slots are per-kernel __device__ globals: launches of the SAME kernel on
+// the same device must be stream-ordered (they are: one stream per engine).
+struct TfcRedSlot { double acc; unsigned cnt; unsigned pad; };
+__device__ __forceinline__ void tfc_block_commit(TfcRedSlot* slot, double partial, float* out) {
+  atomicAdd(&slot->acc, partial);
+  __threadfence();
+  const unsigned t = atomicAdd(&slot->cnt, 1u);
+  if (t == gridDim.x * gridDim.y * gridDim.z - 1) {
+    __threadfence();
+    const double tot = atomicAdd(&slot->acc, 0.0);
+    atomicExch(reinterpret_cast<unsigned long long*>(&slot->acc), 0ull);
+    atomicExch(&slot->cnt, 0u);
+    out[0] += (float)tot;
+  }
+}

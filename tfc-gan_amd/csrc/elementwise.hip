@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(256) tfc_sn_bwd_apply_kernel(const float* __re
 //   mode 0 (G): loss = mean BCE(x, t1);                da = dL/dx
 //   mode 1 (D): loss = 0.5*[mean BCE(x,t1) + mean BCE(-x,t2)];  da = dL/dx, db = -dL/dx
 // ---------------------------------------------------------------------------------------------------
+static __device__ TfcRedSlot g_bce_slot;
 __device__ __forceinline__ float bce_logits(float x, float t) { return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))); }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 template <typename T>
@@ -446,7 +447,7 @@ tfc_bce_rel_kernel(const T* __restrict__ a, const T* __restrict__ b, int n, int 
   l = wave_sum(l);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * invn);
+  if (threadIdx.x == 0) tfc_block_commit(&g_bce_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (double)n, loss);
 }
 
 // Adam (torch.optim.Adam defaults: no weight decay, no amsgrad; reference :461-462)

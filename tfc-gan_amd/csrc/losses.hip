@@ -12,6 +12,7 @@
 // grad wrt anchor (fake):  [hinge>0] * ((a-p+eps)/d_ap - (a-n+eps)/d_an) * scale
 // ---------------------------------------------------------------------------------------------------
 struct NegIdx { int r[16]; };
+static __device__ TfcRedSlot g_trip_slot, g_l1_slot;
 
 __global__ void __launch_bounds__(256)
 tfc_triplet16_kernel(const float* __restrict__ fake, const float* __restrict__ real, const NegIdx neg, int N, int C,
@@ -49,7 +50,8 @@ tfc_triplet16_kernel(const float* __restrict__ fake, const float* __restrict__ r
   }
   if (lane == 0) red[w] = lsum;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * scale);
+  if (threadIdx.x == 0)
+    tfc_block_commit(&g_trip_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (16.0 * N * C * 64.0), loss);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -135,7 +137,7 @@ tfc_l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, long
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * scale);
+  if (threadIdx.x == 0) tfc_block_commit(&g_l1_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) * (double)scale, out);
 }
 
 // ---------------------------------------------------------------------------------------------------
