@@ -123,6 +123,8 @@ int tfc_prof_collect(int kclass, double* total_ms, double* algorithmic_flop, lon
  * the SAME packed operand stream the kernels consume.  Never called by the product path. */
 int tfc_host_emulate_conv(int op, int pass, int elem_size, const float* x_host, const float* w_host, float* y_host,
                           int N, int H, int W, int Cin, int Cout);   /* pass 2 = wgrad: w_host is dy, y_host is dw */
+/* force the gather-GEMM workgroup tile (0: 128 px x 128 ch, 1: x64, 2: x32; -1: heuristic) so the tests reach every variant */
+int tfc_debug_set_igemm_config(int cfg);
 /* device probe of the MFMA / transposing-read lane maps the kernels rely on (writes 3*64*16 floats) */
 int tfc_probe_mfma(void* stream, float* out);
 

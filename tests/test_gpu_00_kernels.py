@@ -82,9 +82,19 @@ CONV_CASES = [  # op, N, H, W, Cin, Cout
 ]
 
 
+@pytest.fixture
+def force_cfg():
+    def setter(cfg):
+        _lib.check(_lib.load().tfc_debug_set_igemm_config(cfg), "set cfg")
+    yield setter
+    setter(-1)
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
 @pytest.mark.parametrize("dt", [DT_F32, DT_BF16])
 @pytest.mark.parametrize("op,N,H,W,Cin,Cout", CONV_CASES)
-def test_conv_family(op, N, H, W, Cin, Cout, dt):
+def test_conv_family(op, N, H, W, Cin, Cout, dt, cfg, force_cfg):
+    force_cfg(cfg)                                                          # every workgroup-tile variant of the gather GEMM
     seed = op * 1000 + Cin + Cout
     K = Cin * (4 if op == ops.OP_CONVT else 16)
     x = q(rnd((N, Cin, H, W), seed), dt).requires_grad_(True)

@@ -314,7 +314,11 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
   if (int e = check_ptr16(packed, "packed")) return e;
   if (int e = check_pitch(dt, x_pitch, pad8(Cin), "x")) return e;
   if (flags & TFC_EP_TANH_NCHW) { REQUIRE(out_nchw != nullptr, "out_nchw is null"); }
-  else { REQUIRE(y != nullptr, "y is null"); REQUIRE(y_pitch >= Cout, "y pitch %d < Cout %d", y_pitch, Cout); }
+  else {
+    REQUIRE(y != nullptr, "y is null");
+    REQUIRE(y_pitch >= Cout, "y pitch %d < Cout %d", y_pitch, Cout);
+    if (dt == TFC_DT_BF16 && Cout >= 8) REQUIRE(y_pitch % 8 == 0 && (((uintptr_t)y) & 15) == 0, "bf16 outputs are stored in 16-byte units: y must be 16-byte aligned with pitch %% 8 == 0");
+  }
   if (flags & TFC_EP_BIAS) REQUIRE(bias != nullptr, "bias is null");
   if (flags & TFC_EP_STATS) REQUIRE(stats != nullptr, "stats is null");
   const size_t pb = phase_packed_bytes(dt, op, 0, Cin, Cout);
@@ -335,6 +339,7 @@ extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int 
   if (int e = check_ptr16(packed, "packed")) return e;
   if (int e = check_pitch(dt, dy_pitch, pad8(Cout), "dy")) return e;
   REQUIRE(dx != nullptr && dx_pitch >= Cin, "dx null or pitch %d < Cin %d", dx_pitch, Cin);
+  if (dt == TFC_DT_BF16 && Cin >= 8) REQUIRE(dx_pitch % 8 == 0 && (((uintptr_t)dx) & 15) == 0, "bf16 outputs are stored in 16-byte units: dx must be 16-byte aligned with pitch %% 8 == 0");
   REQUIRE((flags & ~TFC_EP_ACCUM) == 0, "dgrad supports only TFC_EP_ACCUM");
   TfcGather d;
   if (int e = build_desc(op, 1, 0, N, H, W, Cin, Cout, dy_pitch, dx_pitch, &d, nullptr)) return e;
@@ -496,6 +501,12 @@ extern "C" int tfc_adam_step(void* stream, float* p, const float* g, float* m, f
   const float bc1 = 1.f - powf(b1, (float)step);
   const float bc2 = 1.f - powf(b2, (float)step);
   CHECK_HIP(tfc_launch_adam(p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, (hipStream_t)stream), "tfc_adam_step");
+  return 0;
+}
+extern int g_tfc_force_cfg;
+extern "C" int tfc_debug_set_igemm_config(int cfg) {
+  REQUIRE(cfg >= -1 && cfg <= 2, "cfg must be -1 (heuristic), 0 (128x128), 1 (128x64) or 2 (128x32)");
+  g_tfc_force_cfg = cfg;
   return 0;
 }
 extern "C" int tfc_probe_mfma(void* stream, float* out) {

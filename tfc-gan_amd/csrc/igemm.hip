@@ -48,9 +48,20 @@ template <> struct Mma<float> {
 
 // ---------------------------------------------------------------------------------------------------
 // forward-type gather GEMM
+//   PAT: compile-time tap pattern of every plane (needs 64-byte chunks, i.e. UPP == 4), 0 = generic run-time tables
+//     1: 16 taps, 4x4 raster (dy = t>>2, dx = t&3)      conv / pad+conv, forward and dgrad
+//     2:  4 taps, dy = 1-(t>>1), dx = 1-(t&1)            transposed-conv forward phases
+//     3:  4 taps, dy = t>>1, dx = t&1                    transposed-conv dgrad parity planes
+//   With PAT != 0 the per-stage body is fully unrolled: every A read is ds_read_b128 base+immediate, the weight stream is
+//   prefetched BD k-substeps ahead through a statically indexed register ring, and nothing scalar is loaded in the loop.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MT, int NT, int WM, int WN>
-__global__ void __launch_bounds__(256)
+template <int PAT> struct TapPat;     // taps enumerated row-major: t = row * COLS + col
+template <> struct TapPat<1> { static constexpr int ROWS = 4, COLS = 4; static constexpr int dy(int r) { return r; } static constexpr int dx(int c) { return c; } };
+template <> struct TapPat<2> { static constexpr int ROWS = 2, COLS = 2; static constexpr int dy(int r) { return 1 - r; } static constexpr int dx(int c) { return 1 - c; } };
+template <> struct TapPat<3> { static constexpr int ROWS = 2, COLS = 2; static constexpr int dy(int r) { return r; } static constexpr int dx(int c) { return c; } };
+
+template <typename T, int MT, int NT, int WM, int WN, int PAT>
+__global__ void __launch_bounds__(256, 3)
 tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __restrict__ wp, T* out,
                  const float* __restrict__ bias, float* stats, float* out_nchw,
                  int flags, int NB32, int nblkN, int buf_bytes, int total_sub) {
@@ -60,6 +71,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   constexpr int ES = sizeof(T);
   constexpr int UE = 16 / ES;
   constexpr int P = TFC_LDS_P;
+  constexpr int BD = 4;                                          // weight-stream prefetch distance (k-substeps), PAT != 0
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -67,10 +79,10 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, r = lane & 31;
 
-  const int PB = tfc_pb(d.Cin_pad, ES);
+  const int PB = PAT ? 64 : tfc_pb(d.Cin_pad, ES);
   const int UPP = PB >> 4;
   const int upp_shift = (UPP == 4) ? 2 : (UPP == 2 ? 1 : 0);
-  const int PS = tfc_ps(PB);
+  const int PS = PAT ? 80 : tfc_ps(PB);
   const int CK = PB / ES;
   const int nchunks = (d.Cin_pad * ES) / PB;
   const int nst = nchunks * d.nplanes;
@@ -85,7 +97,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   const int nb0 = (nb_blk * WN + wn) * NT;                     // first 32-channel block of this wave
 
   // A-operand lane base inside a halo buffer
-  const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * PS;
+  const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * PS + (PAT ? h * 16 : 0);
   const int MSTRIDE = 2 * P * PS;
 
   f32x16_t acc[MT][NT];
@@ -126,71 +138,114 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
       if (hoff[i] >= 0) *reinterpret_cast<uint4*>(buf + hoff[i]) = hv[i];
   };
 
-  // ---- weight stream ----
-  const uint4* wlane = wp + (size_t)nb0 * 64 + lane;
-  const size_t wstep = (size_t)NB32 * 64;
+  // ---- weight stream: wave-uniform base (scalar registers) + constant per-lane offset; the stream carries TFC_WPAD
+  //      k-substeps of slack after its last real one, so the prefetch never needs a bounds check ----
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wp);
+  const unsigned laneoff = (unsigned)(nb0 * 64 + lane) * 16u;
+  const size_t wstep_b = (size_t)NB32 * 1024;
   auto loadB = [&](int gs, uint4 (&b)[NT]) {
-    const int g = gs < total_sub ? gs : total_sub - 1;
+    const unsigned char* pw = wbase + (size_t)gs * wstep_b;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = wlane[(size_t)g * wstep + nt * 64];
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const uint4*>(pw + laneoff + nt * 1024);
   };
 
-  uint4 b0r[NT], b1r[NT];
-  loadB(0, b0r);
-  loadB(1, b1r);
-  halo_load(0);
-  halo_store(smem);
-  __syncthreads();
-
-  int gs = 0;
-  for (int st = 0; st < nst; ++st) {
-    const bool more = (st + 1) < nst;
-    if (more) halo_load(st + 1);
-    const unsigned char* buf = smem + (st & 1) * buf_bytes + laneBase;
-    const int pl = st % d.nplanes;
-    const TfcPlane& pd = d.plane[pl];
-    const int nsub = tfc_nsub(pd.ntaps, PB);                    // even by construction
-    for (int s = 0; s < nsub; s += 2) {
-      // ---- substep s (weights in b0r) ----
-      {
-        const int u0 = 2 * s, u1 = u0 + 1;
-        const int t0 = u0 >> upp_shift, t1 = u1 >> upp_shift;
-        const int off0 = (pd.tap_dy[t0] * P + pd.tap_dx[t0]) * PS + (u0 & (UPP - 1)) * 16;
-        const int off1 = (pd.tap_dy[t1] * P + pd.tap_dx[t1]) * PS + (u1 & (UPP - 1)) * 16;
-        const int off = h ? off1 : off0;
-        uint4 a[MT];
+  if constexpr (PAT != 0) {
+    constexpr int NSR = TapPat<PAT>::COLS * 2;                   // k-substeps per filter row (2 per tap: 4 units of 16 B)
+    static_assert(NSR % BD == 0, "register ring must realign every filter row");
+    uint4 br[BD][NT];
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const uint4*>(buf + off + mi * MSTRIDE);
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mi], b0r[nt], acc[mi][nt]);
-        loadB(gs + 2, b0r);
-      }
-      // ---- substep s+1 (weights in b1r) ----
-      {
-        const int u0 = 2 * s + 2, u1 = u0 + 1;
-        const int t0 = u0 >> upp_shift, t1 = u1 >> upp_shift;
-        const int off0 = (pd.tap_dy[t0] * P + pd.tap_dx[t0]) * PS + (u0 & (UPP - 1)) * 16;
-        const int off1 = (pd.tap_dy[t1] * P + pd.tap_dx[t1]) * PS + (u1 & (UPP - 1)) * 16;
-        const int off = h ? off1 : off0;
-        uint4 a[MT];
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const uint4*>(buf + off + mi * MSTRIDE);
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mi], b1r[nt], acc[mi][nt]);
-        loadB(gs + 3, b1r);
-      }
-      gs += 2;
-    }
-    if (more) halo_store(smem + ((st + 1) & 1) * buf_bytes);
+    for (int i = 0; i < BD; ++i) loadB(i, br[i]);
+    halo_load(0);
+    halo_store(smem);
     __syncthreads();
+    int gs = 0;
+    for (int st = 0; st < nst; ++st) {
+      const bool more = (st + 1) < nst;
+      if (more) halo_load(st + 1);
+      const unsigned char* buf = smem + (st & 1) * buf_bytes + laneBase;
+#pragma unroll 1
+      for (int row = 0; row < TapPat<PAT>::ROWS; ++row) {
+        const unsigned char* rbuf = buf + (PAT == 2 ? (1 - row) : row) * (P * 80);
+        uint4 a[2][MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) a[0][mi] = *reinterpret_cast<const uint4*>(rbuf + TapPat<PAT>::dx(0) * 80 + mi * (2 * P * 80));
+#pragma unroll
+        for (int s = 0; s < NSR; ++s) {
+          if (s + 1 < NSR) {                                     // A fragments one k-substep ahead
+            const int off = TapPat<PAT>::dx((s + 1) >> 1) * 80 + ((s + 1) & 1) * 32;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) a[(s + 1) & 1][mi] = *reinterpret_cast<const uint4*>(rbuf + off + mi * (2 * P * 80));
+          }
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[s & 1][mi], br[s % BD][nt], acc[mi][nt]);
+          loadB(gs + s + BD, br[s % BD]);                        // weights BD k-substeps ahead
+          asm volatile("" ::: "memory");                         // keep the issue order: hipcc otherwise sinks the prefetch to its use
+        }
+        gs += NSR;
+      }
+      if (more) halo_store(smem + ((st + 1) & 1) * buf_bytes);
+      __syncthreads();
+    }
+  } else {
+    uint4 b0r[NT], b1r[NT];
+    loadB(0, b0r);
+    loadB(1, b1r);
+    halo_load(0);
+    halo_store(smem);
+    __syncthreads();
+    int gs = 0;
+    for (int st = 0; st < nst; ++st) {
+      const bool more = (st + 1) < nst;
+      if (more) halo_load(st + 1);
+      const unsigned char* buf = smem + (st & 1) * buf_bytes + laneBase;
+      const int pl = st % d.nplanes;
+      const TfcPlane& pd = d.plane[pl];
+      const int nsub = tfc_nsub(pd.ntaps, PB);                    // even by construction
+      for (int s = 0; s < nsub; s += 2) {
+        {
+          const int u0 = 2 * s, u1 = u0 + 1;
+          const int t0 = u0 >> upp_shift, t1 = u1 >> upp_shift;
+          const int off0 = (pd.tap_dy[t0] * P + pd.tap_dx[t0]) * PS + (u0 & (UPP - 1)) * 16;
+          const int off1 = (pd.tap_dy[t1] * P + pd.tap_dx[t1]) * PS + (u1 & (UPP - 1)) * 16;
+          const int off = h ? off1 : off0;
+          uint4 a[MT];
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const uint4*>(buf + off + mi * MSTRIDE);
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mi], b0r[nt], acc[mi][nt]);
+          loadB(gs + 2, b0r);
+        }
+        {
+          const int u0 = 2 * s + 2, u1 = u0 + 1;
+          const int t0 = u0 >> upp_shift, t1 = u1 >> upp_shift;
+          const int off0 = (pd.tap_dy[t0] * P + pd.tap_dx[t0]) * PS + (u0 & (UPP - 1)) * 16;
+          const int off1 = (pd.tap_dy[t1] * P + pd.tap_dx[t1]) * PS + (u1 & (UPP - 1)) * 16;
+          const int off = h ? off1 : off0;
+          uint4 a[MT];
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) a[mi] = *reinterpret_cast<const uint4*>(buf + off + mi * MSTRIDE);
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mi], b1r[nt], acc[mi][nt]);
+          loadB(gs + 3, b1r);
+        }
+        gs += 2;
+      }
+      if (more) halo_store(smem + ((st + 1) & 1) * buf_bytes);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----
   const float* bias_p = (flags & TFC_EP_BIAS) ? bias : nullptr;
+  constexpr bool STAGED = (ES == 2);                             // bf16: transpose through LDS, store whole 16-byte units
+  constexpr int BN = 32 * NT * WN;
+  constexpr int ROWP = BN * ES + 16;                             // LDS bytes per pixel row of the staged tile
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (nb0 + nt) * 32 + r;
@@ -206,7 +261,10 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         const int a = a0 + ty, b = b0 + tx;
         const bool ok = nok && a < d.GH && b < d.GW;
         float v = acc[mi][nt][j] + bv;
-        if (ok) {
+        if (STAGED && !(flags & TFC_EP_TANH_NCHW)) {
+          if (ok) { s1 += v; s2 += v * v; }
+          *reinterpret_cast<bf16_t*>(smem + (ty * TFC_TILE_W + tx) * ROWP + ((wn * NT + nt) * 32 + r) * 2) = f32_to_bf16(v);
+        } else if (ok) {
           const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
           if (flags & TFC_EP_TANH_NCHW) {
             out_nchw[(((size_t)img * d.Nout + n) * d.OH + oy) * d.OW + ox] = tanhf(v);
@@ -225,6 +283,44 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
       if (h == 0 && nok) {
         atomicAdd(&stats[((size_t)img * d.Nout + n) * 2 + 0], s1);
         atomicAdd(&stats[((size_t)img * d.Nout + n) * 2 + 1], s2);
+      }
+    }
+  }
+  if (STAGED && !(flags & TFC_EP_TANH_NCHW)) {
+    __syncthreads();
+    constexpr int UPR = BN / 8;                                  // 16-byte units per pixel row of the tile
+    const int nbase = nb_blk * BN;
+#pragma unroll 2
+    for (int idx = tid; idx < 128 * UPR; idx += 256) {
+      const int pix = idx / UPR, u = idx - pix * UPR;
+      const int ty = pix >> 4, tx = pix & 15;
+      const int a = a0 + ty, b = b0 + tx;
+      const int n0 = nbase + u * 8;
+      if (a < d.GH && b < d.GW && n0 < d.Nout) {
+        const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+        T* po = out + ((size_t)(img * d.OH + oy) * d.OW + ox) * d.out_pitch + n0;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + pix * ROWP + u * 16);
+        if (n0 + 8 <= d.Nout) {
+          if (flags & TFC_EP_ACCUM) {
+            float f[8], g[8];
+            unpack16<bf16_t>(v, f);
+            unpack16<bf16_t>(*reinterpret_cast<const uint4*>(po), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+            v = pack16<bf16_t>(f);
+          }
+          *reinterpret_cast<uint4*>(po) = v;
+        } else {                                                 // ragged tail (Nout not a multiple of 8): element stores
+          float f[8];
+          unpack16<bf16_t>(v, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n0 + e < d.Nout) {
+              float fe = f[e];
+              if (flags & TFC_EP_ACCUM) fe += ElemTraits<T>::ld(po + e);
+              ElemTraits<T>::st(po + e, fe);
+            }
+        }
       }
     }
   }
@@ -482,7 +578,7 @@ int tfc_nb32(int nout) { return (nout + 31) / 32; }
 // NB32 of the packed stream is rounded up to the widest workgroup N extent in use (4 blocks) so every config can read it
 int tfc_nb32_padded(int nout) { int nb = tfc_nb32(nout); return nb <= 1 ? 1 : (nb <= 2 ? 2 : (nb + 3) / 4 * 4); }
 size_t tfc_packed_bytes(const TfcGather& d, int es) {
-  return (size_t)tfc_total_substeps(d, es) * tfc_nb32_padded(d.Nout) * 64 * 16;
+  return (size_t)(tfc_total_substeps(d, es) + TFC_WPAD) * tfc_nb32_padded(d.Nout) * 64 * 16;
 }
 
 template <typename T>
@@ -500,8 +596,32 @@ hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const flo
                            : launch_pack_t<float>(d, w, scale, wp, Nreal, Creal, sn, sc, st);
 }
 
-template <typename T, int MT, int NT, int WM, int WN>
-static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
+// which compile-time tap pattern (if any) a descriptor matches
+static int match_pattern(const TfcGather& d, int es) {
+  if (tfc_pb(d.Cin_pad, es) != 64) return 0;
+  int pat = -1;
+  for (int pl = 0; pl < d.nplanes; ++pl) {
+    const TfcPlane& p = d.plane[pl];
+    int m = 0;
+    if (p.ntaps == 16) {
+      m = 1;
+      for (int t = 0; t < 16; ++t) if (p.tap_dy[t] != (t >> 2) || p.tap_dx[t] != (t & 3)) m = 0;
+    } else if (p.ntaps == 4) {
+      bool p2 = true, p3 = true;
+      for (int t = 0; t < 4; ++t) {
+        if (p.tap_dy[t] != 1 - (t >> 1) || p.tap_dx[t] != 1 - (t & 1)) p2 = false;
+        if (p.tap_dy[t] != (t >> 1) || p.tap_dx[t] != (t & 1)) p3 = false;
+      }
+      m = p2 ? 2 : (p3 ? 3 : 0);
+    }
+    if (m == 0 || (pat != -1 && pat != m)) return 0;
+    pat = m;
+  }
+  return pat < 0 ? 0 : pat;
+}
+
+template <typename T, int MT, int NT, int WM, int WN, int PAT>
+static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
                                    float* stats, float* out_nchw, int flags, hipStream_t st) {
   constexpr int ES = sizeof(T);
   const int NB32 = tfc_nb32_padded(d.Nout);
@@ -511,18 +631,46 @@ static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const voi
   for (int pl = 0; pl < d.nplanes; ++pl) maxhh = d.plane[pl].hh > maxhh ? d.plane[pl].hh : maxhh;
   const int PS = tfc_ps(tfc_pb(d.Cin_pad, ES));
   const int buf_bytes = maxhh * TFC_LDS_P * PS;
+  int lds = 2 * buf_bytes;
+  if (ES == 2) {                                                 // staged epilogue tile
+    const int ep = 128 * (32 * NT * WN * ES + 16);
+    lds = lds > ep ? lds : ep;
+  }
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
   const int total_sub = tfc_total_substeps(d, ES);
-  hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN>), dim3(ntiles * nblkN), dim3(256), 2 * buf_bytes, st, d,
+  hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
                      (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, flags, NB32, nblkN, buf_bytes, total_sub);
   return hipGetLastError();
 }
+
+template <typename T, int MT, int NT, int WM, int WN>
+static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
+                                   float* stats, float* out_nchw, int flags, hipStream_t st) {
+  switch (match_pattern(d, sizeof(T))) {
+    case 1: return launch_igemm_pat<T, MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+    case 2: return launch_igemm_pat<T, MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+    case 3: return launch_igemm_pat<T, MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+    default: return launch_igemm_pat<T, MT, NT, WM, WN, 0>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  }
+}
+
+// Tile-shape choice: 128 pixels x {128, 64, 32} channels. Wider N tiles reuse each A fragment more, but deep / up-path layers
+// have so few pixel tiles that a 128-wide tile leaves most of the 256 CUs idle -> narrow the tile until the grid has >= ~2
+// workgroups per CU (or the narrowest tile is reached).
+int g_tfc_force_cfg = -1;                                        // test hook (tfc_debug_set_igemm_config): -1 = heuristic
 
 template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
                                  float* stats, float* out_nchw, int flags, hipStream_t st) {
   const int nb = tfc_nb32(d.Nout);
-  if (nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if (g_tfc_force_cfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if ((g_tfc_force_cfg == 0 || g_tfc_force_cfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if (g_tfc_force_cfg >= 0) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+  const int target = 512;
+  if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if (nb >= 2 && (ntiles * ((nb + 1) / 2) >= target || nb < 4)) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if (nb >= 4 && ntiles * nb < target / 2) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
   if (nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
   return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
 }

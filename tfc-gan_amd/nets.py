@@ -172,6 +172,9 @@ class GeneratorCore:
             hook("final.2.bias")
         g_cat = new_act(N, ctx.u5.H, ctx.u5.W, ctx.u5.pitch, dt, dev)
         ops.conv_dgrad(dt, OP_UPCONV, dyf, N, ctx.u5.H, ctx.u5.W, 128, ch, self.packed["final"]["dgrad"], g_cat)
+        dbg = getattr(self, "debug", None)
+        if dbg is not None:
+            dbg["dyf"], dbg["g_u5"] = dyf, g_cat
         g_skip = [None] * 6                                       # gradient window of d1..d5 (views), g_d6 separately
         for j in range(4, -1, -1):
             name, cin, cout, drop, skip = G_UP[j]
@@ -188,6 +191,8 @@ class GeneratorCore:
             d_rawT = new_act(N, H, H, cout, dt, dev)
             ops.act_bwd(dt, 0, d_blur, None, N, H, H, cout, d_rawT, stats=None, slope=1.0, pool=1)
             key = f"{name}.model.0.weight"
+            if dbg is not None:
+                dbg[f"{name}.d_blur"], dbg[f"{name}.d_rawT"] = d_blur, d_rawT
             self._ws = ops.conv_wgrad(dt, OP_CONVT, uin, d_rawT, cin, cout, grads[key], accumulate, self._ws)
             if hook:
                 hook(key)
