@@ -13,31 +13,6 @@
 __device__ __forceinline__ float blur_w(int k) { return (k == 0 || k == 3) ? 0.125f : 0.375f; }
 __device__ __forceinline__ int reflect_idx(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
 
-// For input coordinate y (0..n-1) of a reflect-padded blur with `stride`, list the (output index, weight) pairs that
-// read it: padded coordinate aliases p of y are y itself, -1 (if y==1), n (if y==n-2), n+1 (if y==n-3).
-__device__ __forceinline__ int blur_transpose_taps(int y, int n, int no, int stride, int* oidx, float* w) {
-  int cnt = 0;
-  int alias[4];
-  int na = 0;
-  alias[na++] = y;
-  if (y == 1) alias[na++] = -1;
-  if (y == n - 2) alias[na++] = n;
-  if (y == n - 3) alias[na++] = n + 1;
-  for (int ai = 0; ai < na; ++ai) {
-    const int p = alias[ai];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int t = p + 1 - k;                                   // = o*stride
-      if (t < 0) continue;
-      if (stride == 2 && (t & 1)) continue;
-      const int o = stride == 2 ? (t >> 1) : t;
-      if (o < no) { oidx[cnt] = o; w[cnt] = blur_w(k); ++cnt; }
-    }
-  }
-  return cnt;
-}
-
-
 // block = 256 threads = PPB pixels x CV channel vectors; grid = (pixel blocks, N); grid-stride over pixels
 template <typename T, bool STATS_OUT>
 __global__ void __launch_bounds__(256)
@@ -181,24 +156,54 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
           for (int e = 0; e < UE; ++e) g[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? g[e] * p.drop_scale : 0.f;
         }
       } else {
-        int oy[8], ox[8];
-        float wy[8], wx[8];
-        const int ny = blur_transpose_taps(y, p.H, p.Ho, p.pool, oy, wy);
-        const int nx = blur_transpose_taps(xq, p.W, p.Wo, p.pool, ox, wx);
-        for (int i = 0; i < ny; ++i)
-          for (int j = 0; j < nx; ++j) {
-            const int opix = oy[i] * p.Wo + ox[j];
-            float v[UE];
-            unpack16<T>(*reinterpret_cast<const uint4*>(dn + (size_t)opix * p.o_pitch + cv * UE), v);
-            const float w = wy[i] * wx[j];
-            if (p.drop_thresh24) {
-              const uint32_t base = (uint32_t)(((size_t)n * nopix + opix) * p.C + cv * UE);
+        auto tap = [&](int oyy, int oxx, float w) {
+          const int opix = oyy * p.Wo + oxx;
+          float v[UE];
+          unpack16<T>(*reinterpret_cast<const uint4*>(dn + (size_t)opix * p.o_pitch + cv * UE), v);
+          if (p.drop_thresh24) {
+            const uint32_t base = (uint32_t)(((size_t)n * nopix + opix) * p.C + cv * UE);
 #pragma unroll
-              for (int e = 0; e < UE; ++e) v[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? v[e] * p.drop_scale : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < UE; ++e) g[e] += w * v[e];
+            for (int e = 0; e < UE; ++e) v[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? v[e] * p.drop_scale : 0.f;
           }
+#pragma unroll
+          for (int e = 0; e < UE; ++e) g[e] += w * v[e];
+        };
+        const bool yin = y >= 2 && y <= p.H - 4, xin = xq >= 2 && xq <= p.W - 4;
+        if (p.pool == 2 && yin && xin) {
+          // interior of a stride-2 BlurPool: exactly two outputs per dimension read this input, with taps {3/8, 1/8}
+          const int oy0 = (y + 1) >> 1, ox0 = (xq + 1) >> 1;
+          const float wy0 = (y & 1) ? 0.125f : 0.375f, wx0 = (xq & 1) ? 0.125f : 0.375f;
+          const float wy1 = 0.5f - wy0, wx1 = 0.5f - wx0;
+          tap(oy0, ox0, wy0 * wx0);
+          tap(oy0, ox0 - 1, wy0 * wx1);
+          tap(oy0 - 1, ox0, wy1 * wx0);
+          tap(oy0 - 1, ox0 - 1, wy1 * wx1);
+        } else {
+          // border (reflect-pad aliases) and stride-1 blur: enumerate (alias, tap) pairs; alias a: 0 -> p = y, 1 -> p = -1 (y == 1),
+          // 2 -> p = n (y == n-2), 3 -> p = n+1 (y == n-3)
+          const int st = p.pool;
+          for (int ay = 0; ay < 4; ++ay) {
+            if ((ay == 1 && y != 1) || (ay == 2 && y != p.H - 2) || (ay == 3 && y != p.H - 3)) continue;
+            const int py = ay == 0 ? y : (ay == 1 ? -1 : (ay == 2 ? p.H : p.H + 1));
+            for (int ky = 0; ky < 4; ++ky) {
+              const int ty = py + 1 - ky;
+              if (ty < 0 || (st == 2 && (ty & 1))) continue;
+              const int oyy = st == 2 ? (ty >> 1) : ty;
+              if (oyy >= p.Ho) continue;
+              for (int ax = 0; ax < 4; ++ax) {
+                if ((ax == 1 && xq != 1) || (ax == 2 && xq != p.W - 2) || (ax == 3 && xq != p.W - 3)) continue;
+                const int px = ax == 0 ? xq : (ax == 1 ? -1 : (ax == 2 ? p.W : p.W + 1));
+                for (int kx = 0; kx < 4; ++kx) {
+                  const int tx = px + 1 - kx;
+                  if (tx < 0 || (st == 2 && (tx & 1))) continue;
+                  const int oxx = st == 2 ? (tx >> 1) : tx;
+                  if (oxx >= p.Wo) continue;
+                  tap(oyy, oxx, blur_w(ky) * blur_w(kx));
+                }
+              }
+            }
+          }
+        }
       }
       float xh[UE];
       if (use_x) {

@@ -337,7 +337,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 template <typename T> struct WgradFrag;
 
 template <typename T, int TPW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restrict__ in, float* dwacc,
                  int Nn_pad, int Nn_real, int Cw_real, int nbw, int ncb, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
