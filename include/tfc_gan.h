@@ -49,12 +49,14 @@ int tfc_abi_version(void);
 size_t tfc_conv_packed_bytes(int dt, int op, int pass, int Cin, int Cout);
 int tfc_conv_pack(void* stream, int dt, int op, int pass, const float* w, const float* scale, void* packed, int Cin, int Cout);
 
-/* ---- forward: y = op(x) ; x: [N][H][W][x_pitch], y: [N][OH][OW][y_pitch] (OH = H-1 | H | 2H | 2H) ---------------- */
+/* ---- forward: y = oscale * op(x) + bias ; x: [N][H][W][x_pitch], y: [N][OH][OW][y_pitch] (OH = H-1 | H | 2H | 2H) ---
+ * oscale: nullable DEVICE scalar multiplying the accumulator before the bias -- 1/sigma of spectral_norm (P16:188), so the
+ * discriminator's operand streams are packed once per weight update and not once per forward. */
 int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
-                 const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, int flags);
-/* ---- input gradient: dx = op^T(dy) (flags: TFC_EP_ACCUM) -------------------------------------------------------- */
+                 const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags);
+/* ---- input gradient: dx = oscale * op^T(dy) (flags: TFC_EP_ACCUM) ------------------------------------------------ */
 int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
-                   const void* packed, void* dx, int dx_pitch, int flags);
+                   const void* packed, void* dx, int dx_pitch, const float* oscale, int flags);
 /* ---- weight gradient: dw (torch layout, fp32) = or += x (*) dy ; ws: tfc_conv_wgrad_ws_bytes() scratch ----------- */
 size_t tfc_conv_wgrad_ws_bytes(int op, int Cin, int Cout);
 int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, const void* dy, int dy_pitch, int N, int H, int W,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_errors_are_loud():
     lib = _lib.load()
-    rc = lib.tfc_conv_fwd(None, 7, 0, None, 0, 1, 8, 8, 8, 8, None, None, 0, None, None, None, 0)
+    rc = lib.tfc_conv_fwd(None, 7, 0, None, 0, 1, 8, 8, 8, 8, None, None, 0, None, None, None, None, 0)
     assert rc != 0 and b"dtype" in lib.tfc_last_error()
     with pytest.raises(T.TfcError):
         _lib.check(rc, "tfc_conv_fwd")

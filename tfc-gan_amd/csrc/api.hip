@@ -25,7 +25,7 @@ int tfc_nb32(int nout);
 int tfc_nb32_padded(int nout);
 size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
-hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, int flags, hipStream_t st);
+hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
 hipError_t tfc_launch_wgrad_finish(const float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
 hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st);
@@ -161,7 +161,7 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
         d.GH = OH; d.GW = OW;
         p.dy0 = o0; p.dx0 = o0; p.hh = 11; p.hw = 19; p.ntaps = 16;
         for (int ky = 0; ky < 4; ++ky)
-          for (int kx = 0; kx < 4; ++kx) { const int t = ky * 4 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_slot[t] = t; }
+          for (int kx = 0; kx < 4; ++kx) { const int t = ky * 4 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_mask[t] = 1 << t; }
         if (wm) *wm = {Cout, Cin, (long long)Cin * 16, 16};
         break;
       }
@@ -172,18 +172,25 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
           for (int jx = 0; jx < 2; ++jx) {
             const int t = jy * 2 + jx;
             p.tap_dy[t] = 1 - jy; p.tap_dx[t] = 1 - jx;
-            p.tap_slot[t] = (1 - py + 2 * jy) * 4 + (1 - px + 2 * jx);
+            p.tap_mask[t] = 1 << ((1 - py + 2 * jy) * 4 + (1 - px + 2 * jx));
           }
         if (wm) *wm = {Cout, Cin, 16, (long long)Cout * 16};   // ConvTranspose2d weight [Cin][Cout][4][4]
         break;
       }
       case TFC_OP_UPCONV: {
+        // out[2a+p] reads source row a + off(p,k): the 4 filter rows hit only 2 (p=0) or 3 (p=1) distinct source rows, so the
+        // duplicated taps are collapsed (their weights add): 2x2 / 2x3 / 3x2 / 3x3 gather taps instead of 16 per phase
         d.GH = H; d.GW = W; d.OS = 2; d.OOY = py; d.OOX = px;
-        p.dy0 = -1; p.dx0 = -1; p.hh = 10; p.hw = 18; p.ntaps = 16;
-        for (int ky = 0; ky < 4; ++ky)
-          for (int kx = 0; kx < 4; ++kx) {
-            const int t = ky * 4 + kx;
-            p.tap_dy[t] = kUpOff[py][ky] + 1; p.tap_dx[t] = kUpOff[px][kx] + 1; p.tap_slot[t] = t;
+        const int ny = py ? 3 : 2, nx = px ? 3 : 2;
+        p.dy0 = -1; p.dx0 = -1; p.hh = 8 + ny - 1; p.hw = 16 + nx - 1; p.ntaps = ny * nx;
+        for (int iy = 0; iy < ny; ++iy)
+          for (int ix = 0; ix < nx; ++ix) {
+            const int t = iy * nx + ix;
+            int mask = 0;
+            for (int ky = 0; ky < 4; ++ky)
+              for (int kx = 0; kx < 4; ++kx)
+                if (kUpOff[py][ky] + 1 == iy && kUpOff[px][kx] + 1 == ix) mask |= 1 << (ky * 4 + kx);
+            p.tap_dy[t] = iy; p.tap_dx[t] = ix; p.tap_mask[t] = mask;
           }
         if (wm) *wm = {Cout, Cin, (long long)Cin * 16, 16};
         break;
@@ -202,7 +209,7 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
         const int o0 = (op == TFC_OP_CONV) ? -2 : -1;
         p.dy0 = o0; p.dx0 = o0; p.hh = 11; p.hw = 19; p.ntaps = 16;
         for (int ky = 0; ky < 4; ++ky)
-          for (int kx = 0; kx < 4; ++kx) { const int t = ky * 4 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_slot[t] = (3 - ky) * 4 + (3 - kx); }
+          for (int kx = 0; kx < 4; ++kx) { const int t = ky * 4 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_mask[t] = 1 << ((3 - ky) * 4 + (3 - kx)); }
         if (wm) *wm = {Cin, Cout, 16, (long long)Cin * 16};    // Conv2d weight [Cout][Cin][4][4], n = ci, c = co
         break;
       }
@@ -217,7 +224,7 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
             for (int jy = 0; jy < 2; ++jy)
               for (int jx = 0; jx < 2; ++jx) {
                 const int t = jy * 2 + jx;
-                p.tap_dy[t] = jy; p.tap_dx[t] = jx; p.tap_slot[t] = kOf[ppy][jy] * 4 + kOf[ppx][jx];
+                p.tap_dy[t] = jy; p.tap_dx[t] = jx; p.tap_mask[t] = 1 << (kOf[ppy][jy] * 4 + kOf[ppx][jx]);
               }
           }
         if (wm) *wm = {Cin, Cout, (long long)Cout * 16, 16};   // W[ci][co][k]: n = ci, c = co
@@ -233,7 +240,7 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
             for (int ky = 0; ky < 4; ++ky)
               for (int kx = 0; kx < 4; ++kx) {
                 const int t = ky * 4 + kx;
-                p.tap_dy[t] = -kUpOff[ppy][ky] - p.dy0; p.tap_dx[t] = -kUpOff[ppx][kx] - p.dx0; p.tap_slot[t] = t;
+                p.tap_dy[t] = -kUpOff[ppy][ky] - p.dy0; p.tap_dx[t] = -kUpOff[ppx][kx] - p.dx0; p.tap_mask[t] = 1 << t;
               }
           }
         if (wm) *wm = {Cin, Cout, 16, (long long)Cin * 16};    // Conv2d weight [Cout][Cin][4][4]: n = ci, c = co
@@ -251,6 +258,14 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
       if (p.tap_dy[t] < 0 || p.tap_dx[t] < 0 || p.tap_dy[t] + TFC_TILE_H > p.hh || p.tap_dx[t] + TFC_TILE_W > p.hw)
         return fail(-1, "tap %d of plane %d leaves the halo (op %d pass %d)", t, pl, op, pass);
   }
+  return 0;
+}
+
+// the gather-GEMM main loop consumes k-substeps in pairs
+static int check_desc(const TfcGather& d, int dt) {
+  for (int pl = 0; pl < d.nplanes; ++pl)
+    REQUIRE(tfc_nsub(d.plane[pl].ntaps, tfc_pb(d.Cin_pad, es_of(dt))) % 2 == 0,
+            "unsupported shape: %d taps with %d-byte channel chunks give an odd number of k-substeps", d.plane[pl].ntaps, tfc_pb(d.Cin_pad, es_of(dt)));
   return 0;
 }
 
@@ -275,15 +290,20 @@ static int check_ptr16(const void* p, const char* what) {
   return 0;
 }
 
-static size_t phase_packed_bytes(int dt, int op, int pass, int Cin, int Cout) {
-  TfcGather d;
-  if (build_desc(op, pass, 0, 1, 16, 16, Cin, Cout, pad8(Cin), pad8(Cout), &d, nullptr)) return 0;
-  return tfc_packed_bytes(d, es_of(dt));
+// byte offset of phase `ph` inside the packed stream of (op, pass); ph == num_phases gives the total size
+static size_t phase_packed_offset(int dt, int op, int pass, int Cin, int Cout, int ph) {
+  size_t off = 0;
+  for (int q = 0; q < ph; ++q) {
+    TfcGather d;
+    if (build_desc(op, pass, q, 1, 16, 16, Cin, Cout, pad8(Cin), pad8(Cout), &d, nullptr)) return 0;
+    off += tfc_packed_bytes(d, es_of(dt));
+  }
+  return off;
 }
 
 extern "C" size_t tfc_conv_packed_bytes(int dt, int op, int pass, int Cin, int Cout) {
   if (pass < 0 || pass > 1 || op < 0 || op > 3) return 0;
-  return phase_packed_bytes(dt, op, pass, Cin, Cout) * num_phases(op, pass);
+  return phase_packed_offset(dt, op, pass, Cin, Cout, num_phases(op, pass));
 }
 
 extern "C" int tfc_conv_pack(void* stream, int dt, int op, int pass, const float* w, const float* scale, void* packed, int Cin, int Cout) {
@@ -291,12 +311,11 @@ extern "C" int tfc_conv_pack(void* stream, int dt, int op, int pass, const float
   REQUIRE(pass == 0 || pass == 1, "pass must be 0 (fwd) or 1 (dgrad)");
   if (int e = check_ptr16(packed, "packed")) return e;
   REQUIRE(w != nullptr, "w is null");
-  const size_t pb = phase_packed_bytes(dt, op, pass, Cin, Cout);
   for (int ph = 0; ph < num_phases(op, pass); ++ph) {
     TfcGather d;
     WeightMap wm;
     if (int e = build_desc(op, pass, ph, 1, 16, 16, Cin, Cout, pad8(Cin), pad8(Cout), &d, &wm)) return e;
-    CHECK_HIP(tfc_launch_pack(dt, d, w, scale, (char*)packed + ph * pb, wm.Nreal, wm.Creal, wm.sn, wm.sc, (hipStream_t)stream), "tfc_conv_pack");
+    CHECK_HIP(tfc_launch_pack(dt, d, w, scale, (char*)packed + phase_packed_offset(dt, op, pass, Cin, Cout, ph), wm.Nreal, wm.Creal, wm.sn, wm.sc, (hipStream_t)stream), "tfc_conv_pack");
   }
   return 0;
 }
@@ -308,7 +327,7 @@ static double conv_flop(int op, int N, int H, int W, int Cin, int Cout) {
 }
 
 extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
-                            const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, int flags) {
+                            const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags) {
   if (int e = check_common(dt, op, N, H, W, Cin, Cout)) return e;
   if (int e = check_ptr16(x, "x")) return e;
   if (int e = check_ptr16(packed, "packed")) return e;
@@ -321,19 +340,19 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
   }
   if (flags & TFC_EP_BIAS) REQUIRE(bias != nullptr, "bias is null");
   if (flags & TFC_EP_STATS) REQUIRE(stats != nullptr, "stats is null");
-  const size_t pb = phase_packed_bytes(dt, op, 0, Cin, Cout);
   const int nph = num_phases(op, 0);
   ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
   for (int ph = 0; ph < nph; ++ph) {
     TfcGather d;
     if (int e = build_desc(op, 0, ph, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, nullptr)) return e;
-    CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + ph * pb, y, bias, stats, out_nchw, flags, (hipStream_t)stream), "tfc_conv_fwd");
+    if (int e = check_desc(d, dt)) return e;
+    CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
   }
   return 0;
 }
 
 extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
-                              const void* packed, void* dx, int dx_pitch, int flags) {
+                              const void* packed, void* dx, int dx_pitch, const float* oscale, int flags) {
   if (int e = check_common(dt, op, N, H, W, Cin, Cout)) return e;
   if (int e = check_ptr16(dy, "dy")) return e;
   if (int e = check_ptr16(packed, "packed")) return e;
@@ -343,8 +362,9 @@ extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int 
   REQUIRE((flags & ~TFC_EP_ACCUM) == 0, "dgrad supports only TFC_EP_ACCUM");
   TfcGather d;
   if (int e = build_desc(op, 1, 0, N, H, W, Cin, Cout, dy_pitch, dx_pitch, &d, nullptr)) return e;
+  if (int e = check_desc(d, dt)) return e;
   ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
-  CHECK_HIP(tfc_launch_igemm(dt, d, dy, packed, dx, nullptr, nullptr, nullptr, flags, (hipStream_t)stream), "tfc_conv_dgrad");
+  CHECK_HIP(tfc_launch_igemm(dt, d, dy, packed, dx, nullptr, nullptr, nullptr, oscale, flags, (hipStream_t)stream), "tfc_conv_dgrad");
   return 0;
 }
 
@@ -546,7 +566,9 @@ extern "C" int tfc_host_emulate_conv(int op, int pass, int es, const float* x, c
               if (sy < 0 || sy >= d.IH || sx < 0 || sx >= d.IW) continue;
               const float* xp = x + ((size_t)(img * d.IH + sy) * d.IW + sx) * inC;
               for (int n = 0; n < Cout; ++n)
-                for (int c = 0; c < Cin; ++c) acc[((size_t)p.tap_slot[t] * Cout + n) * Cin + c] += (double)dyp[n] * xp[c];
+                for (int c = 0; c < Cin; ++c)
+                  for (int m = p.tap_mask[t]; m; m &= m - 1)
+                    acc[((size_t)__builtin_ctz(m) * Cout + n) * Cin + c] += (double)dyp[n] * xp[c];
             }
           }
     }
@@ -565,11 +587,14 @@ extern "C" int tfc_host_emulate_conv(int op, int pass, int es, const float* x, c
     const int total_units = total_sub * NB32 * 64;
     std::vector<float> wp((size_t)total_units * UE);
     for (int idx = 0; idx < total_units; ++idx) {
-      int n, slot, c0;
-      tfc_pack_locate(d, es, NB32, idx, &n, &slot, &c0);
+      int n, mask, c0;
+      tfc_pack_locate(d, es, NB32, idx, &n, &mask, &c0);
       for (int e = 0; e < UE; ++e) {
         const int c = c0 + e;
-        wp[(size_t)idx * UE + e] = (n < wm.Nreal && c < wm.Creal && slot >= 0) ? w[(long long)n * wm.sn + (long long)c * wm.sc + slot] : 0.f;
+        float a = 0.f;
+        if (n < wm.Nreal && c < wm.Creal)
+          for (int m = mask; m; m &= m - 1) a += w[(long long)n * wm.sn + (long long)c * wm.sc + __builtin_ctz(m)];
+        wp[(size_t)idx * UE + e] = a;
       }
     }
     const int PB = tfc_pb(d.Cin_pad, es), UPP = PB >> 4, CK = PB / es;

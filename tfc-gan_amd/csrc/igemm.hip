@@ -55,15 +55,23 @@ template <> struct Mma<float> {
 //   With PAT != 0 the per-stage body is fully unrolled: every A read is ds_read_b128 base+immediate, the weight stream is
 //   prefetched BD k-substeps ahead through a statically indexed register ring, and nothing scalar is loaded in the loop.
 // ---------------------------------------------------------------------------------------------------
-template <int PAT> struct TapPat;     // taps enumerated row-major: t = row * COLS + col
-template <> struct TapPat<1> { static constexpr int ROWS = 4, COLS = 4; static constexpr int dy(int r) { return r; } static constexpr int dx(int c) { return c; } };
-template <> struct TapPat<2> { static constexpr int ROWS = 2, COLS = 2; static constexpr int dy(int r) { return 1 - r; } static constexpr int dx(int c) { return 1 - c; } };
-template <> struct TapPat<3> { static constexpr int ROWS = 2, COLS = 2; static constexpr int dy(int r) { return r; } static constexpr int dx(int c) { return c; } };
+template <int PAT> struct TapPat;     // taps enumerated row-major: t = row * COLS + col; REV mirrors both axes
+template <int R, int C, bool REV> struct TapPatRC {
+  static constexpr int ROWS = R, COLS = C;
+  static constexpr int dy(int r) { return REV ? R - 1 - r : r; }
+  static constexpr int dx(int c) { return REV ? C - 1 - c : c; }
+};
+template <> struct TapPat<1> : TapPatRC<4, 4, false> {};   // conv / pad+conv, forward and dgrad
+template <> struct TapPat<2> : TapPatRC<2, 2, true> {};    // transposed-conv forward phases
+template <> struct TapPat<3> : TapPatRC<2, 2, false> {};   // transposed-conv dgrad parity planes, upsample-conv phase (0,0)
+template <> struct TapPat<4> : TapPatRC<2, 3, false> {};   // upsample-conv phases with collapsed taps
+template <> struct TapPat<5> : TapPatRC<3, 2, false> {};
+template <> struct TapPat<6> : TapPatRC<3, 3, false> {};
 
 template <typename T, int MT, int NT, int WM, int WN, int PAT>
 __global__ void __launch_bounds__(256, 3)
 tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __restrict__ wp, T* out,
-                 const float* __restrict__ bias, float* stats, float* out_nchw,
+                 const float* __restrict__ bias, float* stats, float* out_nchw, const float* __restrict__ oscale,
                  int flags, int NB32, int nblkN, int buf_bytes, int total_sub) {
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WM * MT == 4, "tile is 4 M-subtiles (128 pixels)");
@@ -71,7 +79,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   constexpr int ES = sizeof(T);
   constexpr int UE = 16 / ES;
   constexpr int P = TFC_LDS_P;
-  constexpr int BD = 4;                                          // weight-stream prefetch distance (k-substeps), PAT != 0
+  constexpr int BD = (PAT == 4 || PAT == 6) ? 2 : 4;              // weight-stream prefetch distance (k-substeps), PAT != 0
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -165,7 +173,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
       const unsigned char* buf = smem + (st & 1) * buf_bytes + laneBase;
 #pragma unroll 1
       for (int row = 0; row < TapPat<PAT>::ROWS; ++row) {
-        const unsigned char* rbuf = buf + (PAT == 2 ? (1 - row) : row) * (P * 80);
+        const unsigned char* rbuf = buf + (PAT == 2 ? (1 - row) : row) * (P * 80);   // == TapPat::dy(row)
         uint4 a[2][MT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) a[0][mi] = *reinterpret_cast<const uint4*>(rbuf + TapPat<PAT>::dx(0) * 80 + mi * (2 * P * 80));
@@ -243,6 +251,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 
   // ---- epilogue ----
   const float* bias_p = (flags & TFC_EP_BIAS) ? bias : nullptr;
+  const float osc = oscale ? *oscale : 1.f;                      // spectral norm: conv(x, W / sigma) = conv(x, W) / sigma
   constexpr bool STAGED = (ES == 2);                             // bf16: transpose through LDS, store whole 16-byte units
   constexpr int BN = 32 * NT * WN;
   constexpr int ROWP = BN * ES + 16;                             // LDS bytes per pixel row of the staged tile
@@ -260,7 +269,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         const int ty = 2 * (wm * MT + mi) + (row & 1), tx = row >> 1;
         const int a = a0 + ty, b = b0 + tx;
         const bool ok = nok && a < d.GH && b < d.GW;
-        float v = acc[mi][nt][j] + bv;
+        float v = acc[mi][nt][j] * osc + bv;
         if (STAGED && !(flags & TFC_EP_TANH_NCHW)) {
           if (ok) { s1 += v; s2 += v * v; }
           *reinterpret_cast<bf16_t*>(smem + (ty * TFC_TILE_W + tx) * ROWP + ((wn * NT + nt) * 32 + r) * 2) = f32_to_bf16(v);
@@ -420,6 +429,7 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
     }
   };
 
+  const int nni = (Nn_pad - nb * 64) > 32 ? 2 : 1;               // second 32-row block empty (e.g. the 3-channel head)? skip its MFMAs
   // lane decode for the transposing reads (bf16) / dword reads (fp32)
   const int grp = lane >> 4, li = lane & 15;
   const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
@@ -444,7 +454,7 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
         }
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {
-          const int tap = wave * TPW + ti;
+          const int tap = ti * 4 + wave;
           if (tap < pd.ntaps) {                                  // wave-uniform
             const unsigned char* pb = hab + ((kt + pd.tap_dy[tap]) * pd.hw + pd.tap_dx[tap]) * ROWB + trLane;
             s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, pb));
@@ -456,8 +466,9 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
             b.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-              acc[ti][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ni]),
-                                                                     __builtin_bit_cast(bf16x8_t, b), acc[ti][ni], 0, 0, 0);
+              if (ni < nni)
+                acc[ti][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ni]),
+                                                                       __builtin_bit_cast(bf16x8_t, b), acc[ti][ni], 0, 0, 0);
           }
         }
       }
@@ -471,12 +482,12 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
         const int ty = px >> 4, tx = px & 15;
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {
-          const int tap = wave * TPW + ti;
+          const int tap = ti * 4 + wave;
           if (tap < pd.ntaps) {
             const float b = *reinterpret_cast<const float*>(hab + ((ty + pd.tap_dy[tap]) * pd.hw + tx + pd.tap_dx[tap]) * ROWB + r * 4);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-              acc[ti][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ni], b, acc[ti][ni], 0, 0, 0);
+              if (ni < nni) acc[ti][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ni], b, acc[ti][ni], 0, 0, 0);
           }
         }
       }
@@ -511,17 +522,19 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
   const int hrow = lane >> 5;
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) {
-    const int tap = wave * TPW + ti;
+    const int tap = ti * 4 + wave;
     if (tap < pd.ntaps) {
-      const int slot = pd.tap_slot[tap];
+      for (int m = pd.tap_mask[tap]; m; m &= m - 1) {              // a collapsed tap feeds every filter tap it stands for
+        const int slot = __ffs(m) - 1;
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int n = nb * 64 + ni * 32 + (j & 3) + 8 * (j >> 2) + 4 * hrow;
-          if (n < Nn_real && c < Cw_real)
-            atomicAdd(&dwacc[((size_t)slot * Nn_real + n) * Cw_real + c], acc[ti][ni][j]);
-        }
+          for (int j = 0; j < 16; ++j) {
+            const int n = nb * 64 + ni * 32 + (j & 3) + 8 * (j >> 2) + 4 * hrow;
+            if (ni < nni && n < Nn_real && c < Cw_real)
+              atomicAdd(&dwacc[((size_t)slot * Nn_real + n) * Cw_real + c], acc[ti][ni][j]);
+          }
+      }
     }
   }
 }
@@ -539,14 +552,17 @@ tfc_pack_w_kernel(const TfcGather d, const float* __restrict__ w, const float* _
   constexpr int UE = 16 / ES;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total_units) return;
-  int n, slot, c0;
-  tfc_pack_locate(d, ES, NB32, idx, &n, &slot, &c0);
+  int n, mask, c0;
+  tfc_pack_locate(d, ES, NB32, idx, &n, &mask, &c0);
   const float scale = scale_ptr ? *scale_ptr : 1.f;
   float v[UE];
 #pragma unroll
   for (int e = 0; e < UE; ++e) {
     const int c = c0 + e;
-    v[e] = (n < Nreal && c < Creal && slot >= 0) ? w[(long long)n * sn + (long long)c * sc + slot] * scale : 0.f;
+    float a = 0.f;
+    if (n < Nreal && c < Creal)
+      for (int m = mask; m; m &= m - 1) a += w[(long long)n * sn + (long long)c * sc + (__ffs(m) - 1)];
+    v[e] = a * scale;
   }
   wp[idx] = pack16<T>(v);
 }
@@ -596,24 +612,25 @@ hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const flo
                            : launch_pack_t<float>(d, w, scale, wp, Nreal, Creal, sn, sc, st);
 }
 
-// which compile-time tap pattern (if any) a descriptor matches
+// which compile-time tap pattern (if any) a descriptor matches (every plane must match the same one)
+static int plane_pattern(const TfcPlane& p) {
+  static const int R[7] = {0, 4, 2, 2, 2, 3, 3}, C[7] = {0, 4, 2, 2, 3, 2, 3}, REV[7] = {0, 0, 1, 0, 0, 0, 0};
+  for (int pat = 1; pat <= 6; ++pat) {
+    if (p.ntaps != R[pat] * C[pat]) continue;
+    bool ok = true;
+    for (int t = 0; t < p.ntaps && ok; ++t) {
+      const int r = t / C[pat], c = t % C[pat];
+      ok = p.tap_dy[t] == (REV[pat] ? R[pat] - 1 - r : r) && p.tap_dx[t] == (REV[pat] ? C[pat] - 1 - c : c);
+    }
+    if (ok) return pat;
+  }
+  return 0;
+}
 static int match_pattern(const TfcGather& d, int es) {
   if (tfc_pb(d.Cin_pad, es) != 64) return 0;
   int pat = -1;
   for (int pl = 0; pl < d.nplanes; ++pl) {
-    const TfcPlane& p = d.plane[pl];
-    int m = 0;
-    if (p.ntaps == 16) {
-      m = 1;
-      for (int t = 0; t < 16; ++t) if (p.tap_dy[t] != (t >> 2) || p.tap_dx[t] != (t & 3)) m = 0;
-    } else if (p.ntaps == 4) {
-      bool p2 = true, p3 = true;
-      for (int t = 0; t < 4; ++t) {
-        if (p.tap_dy[t] != 1 - (t >> 1) || p.tap_dx[t] != 1 - (t & 1)) p2 = false;
-        if (p.tap_dy[t] != (t >> 1) || p.tap_dx[t] != (t & 1)) p3 = false;
-      }
-      m = p2 ? 2 : (p3 ? 3 : 0);
-    }
+    const int m = plane_pattern(d.plane[pl]);
     if (m == 0 || (pat != -1 && pat != m)) return 0;
     pat = m;
   }
@@ -622,7 +639,7 @@ static int match_pattern(const TfcGather& d, int es) {
 
 template <typename T, int MT, int NT, int WM, int WN, int PAT>
 static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                   float* stats, float* out_nchw, int flags, hipStream_t st) {
+                                   float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   constexpr int ES = sizeof(T);
   const int NB32 = tfc_nb32_padded(d.Nout);
   const int per_blk = NT * WN;
@@ -639,18 +656,21 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
   const int total_sub = tfc_total_substeps(d, ES);
   hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
-                     (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, flags, NB32, nblkN, buf_bytes, total_sub);
+                     (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, total_sub);
   return hipGetLastError();
 }
 
 template <typename T, int MT, int NT, int WM, int WN>
 static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                   float* stats, float* out_nchw, int flags, hipStream_t st) {
+                                   float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   switch (match_pattern(d, sizeof(T))) {
-    case 1: return launch_igemm_pat<T, MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-    case 2: return launch_igemm_pat<T, MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-    case 3: return launch_igemm_pat<T, MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-    default: return launch_igemm_pat<T, MT, NT, WM, WN, 0>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+    case 1: return launch_igemm_pat<T, MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    case 2: return launch_igemm_pat<T, MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    case 3: return launch_igemm_pat<T, MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    case 4: return launch_igemm_pat<T, MT, NT, WM, WN, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    case 5: return launch_igemm_pat<T, MT, NT, WM, WN, 5>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    case 6: return launch_igemm_pat<T, MT, NT, WM, WN, 6>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    default: return launch_igemm_pat<T, MT, NT, WM, WN, 0>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   }
 }
 
@@ -661,23 +681,23 @@ int g_tfc_force_cfg = -1;                                        // test hook (t
 
 template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                 float* stats, float* out_nchw, int flags, hipStream_t st) {
+                                 float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   const int nb = tfc_nb32(d.Nout);
-  if (g_tfc_force_cfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-  if ((g_tfc_force_cfg == 0 || g_tfc_force_cfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-  if (g_tfc_force_cfg >= 0) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if (g_tfc_force_cfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if ((g_tfc_force_cfg == 0 || g_tfc_force_cfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (g_tfc_force_cfg >= 0) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
   const int target = 512;
-  if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-  if (nb >= 2 && (ntiles * ((nb + 1) / 2) >= target || nb < 4)) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-  if (nb >= 4 && ntiles * nb < target / 2) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-  if (nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, flags, st);
-  return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+  if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (nb >= 2 && (ntiles * ((nb + 1) / 2) >= target || nb < 4)) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (nb >= 4 && ntiles * nb < target / 2) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
 }
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                            float* stats, float* out_nchw, int flags, hipStream_t st) {
-  return dt == TFC_DT_BF16 ? launch_igemm_t<bf16_t>(d, in, wp, out, bias, stats, out_nchw, flags, st)
-                           : launch_igemm_t<float>(d, in, wp, out, bias, stats, out_nchw, flags, st);
+                            float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? launch_igemm_t<bf16_t>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st)
+                           : launch_igemm_t<float>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
 }
 
 template <typename T>
@@ -686,18 +706,18 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   constexpr int ES = sizeof(T);
   const int nbw = (Nn_pad + 63) / 64, ncb = (d.Cin_pad + 31) / 32;
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
-  // split-K over pixel tiles: aim at ~3 workgroups per CU, at least 2 tiles per workgroup where possible
-  int nsplit = (768 + nbw * ncb - 1) / (nbw * ncb);
+  // split-K over pixel tiles: the kernel runs 2 workgroups per CU (208 VGPRs, 60 KB LDS), so aim at exactly 512 of them --
+  // one full round, no half-empty tail, and the fewest atomic flushes
+  int nsplit = 512 / (nbw * ncb);
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
   const int lds = (2 * 128 * 32 * ES + TFC_MAX_HH * TFC_MAX_HW * 32 * ES) * (ES == 2 ? 2 : 1);
   const dim3 grid(nbw * ncb * nsplit);
-  if (d.plane[0].ntaps <= 4)
-    hipLaunchKernelGGL((tfc_wgrad_kernel<T, 1>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, Nn_pad,
-                       Nn_real, Cw_real, nbw, ncb, nsplit);
-  else
-    hipLaunchKernelGGL((tfc_wgrad_kernel<T, 4>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, Nn_pad,
-                       Nn_real, Cw_real, nbw, ncb, nsplit);
+  const int tpw = (d.plane[0].ntaps + 3) / 4;                    // taps per wave (tap t belongs to wave t % 4)
+#define TFC_WG(TPW_) hipLaunchKernelGGL((tfc_wgrad_kernel<T, TPW_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, \
+                                        Nn_pad, Nn_real, Cw_real, nbw, ncb, nsplit)
+  if (tpw <= 1) TFC_WG(1); else if (tpw == 2) TFC_WG(2); else if (tpw == 3) TFC_WG(3); else TFC_WG(4);
+#undef TFC_WG
   return hipGetLastError();
 }
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad,

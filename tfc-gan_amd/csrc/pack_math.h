@@ -2,8 +2,8 @@
 #pragma once
 #include "tfc_desc.h"
 
-// unit index idx = ((gs*NB32 + nb)*64 + lane)  ->  output channel n, filter slot, first input channel c0 of the 16-B unit
-static inline __host__ __device__ void tfc_pack_locate(const TfcGather& d, int es, int NB32, int idx, int* n, int* slot, int* c0) {
+// unit index idx = ((gs*NB32 + nb)*64 + lane)  ->  output channel n, filter-tap mask, first input channel c0 of the 16-B unit
+static inline __host__ __device__ void tfc_pack_locate(const TfcGather& d, int es, int NB32, int idx, int* n, int* mask, int* c0) {
   const int lane = idx & 63;
   const int rest = idx >> 6;
   const int nb = rest % NB32;
@@ -22,6 +22,6 @@ static inline __host__ __device__ void tfc_pack_locate(const TfcGather& d, int e
   const int u = 2 * gs + h;
   const int tap = u / UPP, g = u % UPP;
   *n = nb * 32 + rn;
-  *slot = d.plane[pl].tap_slot[tap];
+  *mask = d.plane[pl].tap_mask[tap];
   *c0 = cc * CK + g * UE;
 }

@@ -42,7 +42,8 @@ struct TfcPlane {
   int pad_;
   int tap_dy[TFC_MAX_TAPS];   // tap position inside the halo (>= 0)
   int tap_dx[TFC_MAX_TAPS];
-  int tap_slot[TFC_MAX_TAPS]; // which 4x4 filter tap (ky*4+kx) of the torch weight this tap multiplies
+  int tap_mask[TFC_MAX_TAPS]; // bit (ky*4+kx) set for every 4x4 filter tap of the torch weight this gather tap multiplies
+                              // (one bit normally; several when duplicated taps of an upsampled input are collapsed: their weights add)
 };
 
 struct TfcGather {

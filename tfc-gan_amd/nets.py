@@ -239,9 +239,14 @@ class DiscriminatorCore:
         self.head_packed = {}
 
     def repack(self):
+        """operand streams of the UN-normalised weights, once per weight update; 1/sigma is applied in the GEMM epilogue"""
         w = self.params["model.13.weight"]
         self.head_packed["fwd"] = ops.pack_weight(self.dt, OP_PADCONV, 0, w, 512, 1, out=self.head_packed.get("fwd"))
         self.head_packed["dgrad"] = ops.pack_weight(self.dt, OP_PADCONV, 1, w, 512, 1, out=self.head_packed.get("dgrad"))
+        for i, cin, cout in D_BLOCKS:
+            W = self.params[f"model.{i}.parametrizations.weight.original"]
+            self.head_packed[f"f{i}"] = ops.pack_weight(self.dt, OP_CONV, 0, W, cin, cout, out=self.head_packed.get(f"f{i}"))
+            self.head_packed[f"d{i}"] = ops.pack_weight(self.dt, OP_CONV, 1, W, cin, cout, out=self.head_packed.get(f"d{i}"))
 
     def forward(self, img_a, img_b, power_iter=True, save=True):
         """img_a, img_b: fp32 NCHW [N,3,S,S]. Returns (logits View [N,S/16,S/16,pitch 8] channel 0, ctx)."""
@@ -261,10 +266,9 @@ class DiscriminatorCore:
             v = self.buffers[f"model.{i}.parametrizations.weight.0._v"]
             sigma2 = torch.empty(2, dtype=torch.float32, device=dev)
             ops.spectral_norm_step(W, u, v, sigma2, power_iter=power_iter)
-            packed = ops.pack_weight(dt, OP_CONV, 0, W, cin, cout, scale=sigma2[1:])
             h = cur.H
             raw = new_act(N, h - 1, h - 1, cout, dt, dev)
-            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, packed, raw, bias=self.params[f"model.{i}.bias"])
+            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:])
             out = new_act(N, pooled(h - 1), pooled(h - 1), cout, dt, dev)
             ops.act_fwd(dt, raw, out, stats=None, slope=0.2, pool=2)
             ctx.ins.append(cur)
@@ -309,9 +313,8 @@ class DiscriminatorCore:
                     hook(f"model.{i}.parametrizations.weight.original")
                     hook(f"model.{i}.bias")
             if bi > 0 or need_input_grad:
-                packed = ops.pack_weight(dt, OP_CONV, 1, W, cin, cout, scale=sigma2[1:])
                 g_in = new_act(N, xin.H, xin.W, xin.pitch, dt, dev)
-                ops.conv_dgrad(dt, OP_CONV, d_raw, N, xin.H, xin.W, cin, cout, packed, g_in)
+                ops.conv_dgrad(dt, OP_CONV, d_raw, N, xin.H, xin.W, cin, cout, self.head_packed[f"d{i}"], g_in, oscale=sigma2[1:])
                 g_cur = g_in
         if need_input_grad:
             return ops.unpack_nchw(dt, g_cur, self.channels, c0=0)

@@ -103,7 +103,7 @@ def pack_weight(dt, op, pas, w, Cin, Cout, scale=None, out=None):
     return out
 
 
-def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stats=None, out_nchw=None, flags=0):
+def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stats=None, out_nchw=None, flags=0, oscale=None):
     if bias is not None:
         flags |= EP_BIAS
     if stats is not None:
@@ -111,13 +111,13 @@ def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stat
     if out_nchw is not None:
         flags |= EP_TANH_NCHW
     check(lib().tfc_conv_fwd(stream_ptr(), dt, op, x.ptr, x.pitch, x.N, x.H, x.W, Cin, Cout, _p(packed),
-                             None if y is None else y.ptr, 0 if y is None else y.pitch, _p(bias), _p(stats), _p(out_nchw), flags),
+                             None if y is None else y.ptr, 0 if y is None else y.pitch, _p(bias), _p(stats), _p(out_nchw), _p(oscale), flags),
           "tfc_conv_fwd")
 
 
-def conv_dgrad(dt, op, dy: View, N, H, W, Cin, Cout, packed, dx: View, accumulate=False):
+def conv_dgrad(dt, op, dy: View, N, H, W, Cin, Cout, packed, dx: View, accumulate=False, oscale=None):
     check(lib().tfc_conv_dgrad(stream_ptr(), dt, op, dy.ptr, dy.pitch, N, H, W, Cin, Cout, _p(packed), dx.ptr, dx.pitch,
-                               EP_ACCUM if accumulate else 0), "tfc_conv_dgrad")
+                               _p(oscale), EP_ACCUM if accumulate else 0), "tfc_conv_dgrad")
 
 
 def conv_wgrad(dt, op, x: View, dy: View, Cin, Cout, dw, accumulate=False, ws=None):
