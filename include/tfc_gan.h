@@ -68,7 +68,8 @@ int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, con
  *   slope: 0.2 LeakyReLU, 0 ReLU, 1 identity; stats: [N][C][2] (sum, sumsq) of x over H*W; eps 1e-5, biased variance
  *   stats_out (nullable): [N][C][2] += (sum, sumsq) of y  (InstanceNorm that FOLLOWS the blur in UNetUp)
  *   dropout: drop_p in [0,1): counter-based mask of (seed, element index), identical in forward and backward
- * backward : mode 0: dx = g'            (norm == 0)
+ * backward : mode 0: dx = g'            (norm == 0); rstats (nullable) = float[N][C] += per-image column sums of dx = the bias gradient of the
+ *                     convolution that produced x (Discriminator1 blocks, P16:189)
  *            mode 1: rstats[N][C][2] += (sum g', sum g' * xhat)          (InstanceNorm backward, reduction phase)
  *            mode 2: dx = rstd * (g' - mean g' - xhat * mean(g' xhat))   (apply phase)
  *            g' = Blur^T(dropmask * dy) * Act'(xhat) ; x == NULL => Act' = 1
@@ -90,6 +91,12 @@ int tfc_axpby(void* stream, float* out, const float* x, const float* y, long lon
 /* ---- spectral norm: torch.nn.utils.parametrizations.spectral_norm, P16:188 ---------------------------------------- */
 /* W: [R][K] fp32; u[R], v[K] updated in place when power_iter != 0; sigma2 = {sigma, 1/sigma}; ws: (R+K) floats */
 int tfc_spectral_norm_step(void* stream, const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter);
+/* the same for up to 4 layers in 3 launches (host arrays of device pointers / sizes); u_snap / v_snap (nullable arrays of
+ * nullable pointers) receive copies of the updated u, v for the backward of THIS forward call; ws: ..._ws_floats() floats */
+size_t tfc_spectral_norm_batched_ws_floats(int nlayers, const int* R_host, const int* K_host);
+int tfc_spectral_norm_step_batched(void* stream, int nlayers, const float* const* W_host, float* const* u_host, float* const* v_host,
+                                   float* const* sigma2_host, float* const* u_snap_host, float* const* v_snap_host,
+                                   const int* R_host, const int* K_host, float* ws, int power_iter);
 /* gW_orig (=/+=) (G - <G, W/sigma> u v^T) / sigma ; ws: 1 float */
 int tfc_spectral_norm_bwd(void* stream, const float* G, const float* W, const float* u, const float* v, const float* sigma2,
                           float* ws, float* gout, int R, int K, int accumulate);

@@ -1,0 +1,45 @@
+"""Micro-benchmark of individual kernels at BASELINE sizes (batch 32) for rocprofv3 --kernel-trace / --pmc runs.
+usage: python scripts/microbench.py [which ...]   which in {act, igemm, wgrad}"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import tfc_gan_amd as T
+from tfc_gan_amd import ops
+DEV = "cuda:0"
+dt = ops.DT_BF16
+N = 32
+which = sys.argv[1:] or ["act", "igemm", "wgrad"]
+REP = 3
+def rnd(*s):
+    return ops.View(torch.randn(*s, device=DEV).to(torch.bfloat16), s[-1])
+if "act" in which:
+    # Discriminator block 1: raw [32,255,255,64] -> pooled [32,128,128,64]
+    raw = rnd(N, 255, 255, 64); out = ops.new_act(N, 128, 128, 64, dt, DEV); g = rnd(N, 128, 128, 64); dx = ops.new_act(N, 255, 255, 64, dt, DEV)
+    stats = torch.zeros(N, 64, 2, device=DEV); stats[..., 1] = 255 * 255
+    for _ in range(REP):
+        ops.act_fwd(dt, raw, out, stats=None, slope=0.2, pool=2)                      # D / down1 forward
+        ops.act_fwd(dt, raw, out, stats=stats, slope=0.2, pool=2)                     # normalised variant
+        ops.act_bwd(dt, 0, g, raw, N, 255, 255, 64, dx, slope=0.2, pool=2)            # D backward
+    # up5: blur s1 transpose on [32,128,128,64]
+    a = rnd(N, 128, 128, 64); b = ops.new_act(N, 128, 128, 64, dt, DEV)
+    for _ in range(REP):
+        ops.act_bwd(dt, 0, a, None, N, 128, 128, 64, b, slope=1.0, pool=1)
+if "igemm" in which:
+    # down2 / D2: 64 -> 128 @ 128x128 ; D1: 8 -> 64 @ 256x256
+    x = rnd(N, 128, 128, 64); w = torch.randn(128, 64, 4, 4, device=DEV) * 0.03; y = ops.new_act(N, 127, 127, 128, dt, DEV)
+    pk = ops.pack_weight(dt, ops.OP_CONV, 0, w, 64, 128); pkd = ops.pack_weight(dt, ops.OP_CONV, 1, w, 64, 128)
+    gy = rnd(N, 127, 127, 128); gx = ops.new_act(N, 128, 128, 64, dt, DEV)
+    x1 = rnd(N, 256, 256, 8); w1 = torch.randn(64, 6, 4, 4, device=DEV) * 0.1; y1 = ops.new_act(N, 255, 255, 64, dt, DEV)
+    pk1 = ops.pack_weight(dt, ops.OP_CONV, 0, w1, 6, 64)
+    for _ in range(REP):
+        ops.conv_fwd(dt, ops.OP_CONV, x, 64, 128, pk, y)
+        ops.conv_dgrad(dt, ops.OP_CONV, gy, N, 128, 128, 64, 128, pkd, gx)
+        ops.conv_fwd(dt, ops.OP_CONV, x1, 6, 64, pk1, y1)
+if "wgrad" in which:
+    x = rnd(N, 128, 128, 64); gy = rnd(N, 127, 127, 128); dw = torch.empty(128, 64, 4, 4, device=DEV)
+    x3 = rnd(N, 32, 32, 256); gy3 = rnd(N, 31, 31, 512); dw3 = torch.empty(512, 256, 4, 4, device=DEV)
+    for _ in range(REP):
+        ops.conv_wgrad(dt, ops.OP_CONV, x, gy, 64, 128, dw)
+        ops.conv_wgrad(dt, ops.OP_CONV, x3, gy3, 256, 512, dw3)
+torch.cuda.synchronize()
+print("done")

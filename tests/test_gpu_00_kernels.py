@@ -267,6 +267,30 @@ def test_spectral_norm_step_and_backward():
     assert (gout.cpu() - Wr.grad).abs().max().item() <= 1e-4 * Wr.grad.abs().max().item()
 
 
+def test_spectral_norm_batched_matches_oracle():
+    shapes = [(64, 96), (128, 1024), (512, 8192), (256, 2048)]
+    Ws = [rnd(sh, 10 + i, 0.05) for i, sh in enumerate(shapes)]
+    us = [F.normalize(rnd((sh[0],), 20 + i), dim=0) for i, sh in enumerate(shapes)]
+    vs = [F.normalize(rnd((sh[1],), 30 + i), dim=0) for i, sh in enumerate(shapes)]
+    Wd, ud, vd = [w.to(DEV) for w in Ws], [u.to(DEV) for u in us], [v.to(DEV) for v in vs]
+    sig = [torch.zeros(2, device=DEV) for _ in shapes]
+    usn = [torch.zeros_like(u) for u in ud]
+    vsn = [torch.zeros_like(v) for v in vd]
+    ws = None
+    for it in range(3):
+        ws = ops.spectral_norm_step_batched(Wd, ud, vd, sig, power_iter=True, u_snaps=usn, v_snaps=vsn, ws=ws)
+        for i in range(len(shapes)):
+            us[i], vs[i], sigma = O.spectral_norm_step(Ws[i], us[i], vs[i])
+            assert torch.allclose(ud[i].cpu(), us[i], atol=3e-6) and torch.allclose(vd[i].cpu(), vs[i], atol=3e-6), (it, i)
+            assert torch.equal(usn[i], ud[i]) and torch.equal(vsn[i], vd[i])
+            assert abs(sig[i][0].item() - sigma.item()) < 2e-5 * sigma.item() and abs(sig[i][1].item() * sigma.item() - 1) < 2e-5
+    ops.spectral_norm_step_batched(Wd, ud, vd, sig, power_iter=False, ws=ws)          # eval: sigma only, u / v untouched
+    for i in range(len(shapes)):
+        assert torch.allclose(ud[i].cpu(), us[i], atol=3e-6)
+        sigma = torch.dot(us[i], Ws[i] @ vs[i])
+        assert abs(sig[i][0].item() - sigma.item()) < 2e-5 * sigma.item()
+
+
 def test_triplet16_vs_oracle_and_golden(golden):
     g = golden("triplet16")
     fk, rl = O.synthetic_pairs(2, seed=31)

@@ -71,6 +71,9 @@ PROTOTYPES = {
     "tfc_cast": (_i, [_vp, _i, _i, _vp, _vp, _ll]),
     "tfc_axpby": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f]),
     "tfc_spectral_norm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    "tfc_spectral_norm_batched_ws_floats": (_sz, [_i, _c.POINTER(_i), _c.POINTER(_i)]),
+    "tfc_spectral_norm_step_batched": (_i, [_vp, _i, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_vp),
+                                            _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _vp, _i]),
     "tfc_spectral_norm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "tfc_patch16_triplet": (_i, [_vp, _vp, _vp, _c.POINTER(_i), _i, _i, _vp, _vp, _f]),
     "tfc_fft_spectrum": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),

@@ -45,6 +45,15 @@ hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int*
 hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img, int nwin, float* amp, float* pha, int shift, hipStream_t st);
 hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st);
 hipError_t tfc_launch_probe(float* out, hipStream_t st);
+struct SnBatch {
+  const float* W[4];
+  float* u[4]; float* v[4]; float* sigma2[4];
+  float* us[4]; float* vs[4];
+  float* s[4]; float* t[4];
+  int R[4], K[4];
+  int n;
+};
+hipError_t tfc_launch_sn_step_batched(const SnBatch& b, float* ws_t, size_t t_bytes, int power_iter, float eps, hipStream_t st);
 
 // ---- error handling --------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -433,7 +442,7 @@ extern "C" int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int d
   REQUIRE(mode >= 0 && mode <= 2, "bad mode");
   if (int e = check_ptr16(dy, "dy")) return e;
   REQUIRE(!norm || (stats && x), "norm needs stats and x");
-  REQUIRE(mode == 0 || (norm && rstats), "modes 1/2 need norm and rstats");
+  REQUIRE(mode == 0 || (norm && rstats), "modes 1/2 need norm and rstats");   // mode 0: rstats (nullable) = float[C] += column sums of dx
   REQUIRE(mode == 1 || dx, "dx is null");
   const void* xx = x ? x : dy;
   CHECK_HIP(tfc_launch_act_bwd(dt, mode, p, dy, xx, stats, rstats, dx ? dx : (void*)dy, x ? 1 : 0, dx_pitch, (hipStream_t)stream), "tfc_act_bwd");
@@ -481,6 +490,33 @@ extern "C" int tfc_axpby(void* stream, float* out, const float* x, const float* 
 extern "C" int tfc_spectral_norm_step(void* stream, const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter) {
   REQUIRE(W && u && v && sigma2 && ws && R > 0 && K > 0, "bad args");
   CHECK_HIP(tfc_launch_sn_step(W, u, v, sigma2, ws, R, K, power_iter, 1e-12f, (hipStream_t)stream), "tfc_spectral_norm_step");
+  return 0;
+}
+extern "C" size_t tfc_spectral_norm_batched_ws_floats(int nlayers, const int* R, const int* K) {
+  size_t n = 0;
+  for (int i = 0; i < nlayers; ++i) n += (size_t)R[i] + K[i];
+  return n;
+}
+extern "C" int tfc_spectral_norm_step_batched(void* stream, int nlayers, const float* const* W, float* const* u, float* const* v,
+                                              float* const* sigma2, float* const* u_snap, float* const* v_snap, const int* R,
+                                              const int* K, float* ws, int power_iter) {
+  REQUIRE(nlayers >= 1 && nlayers <= 4 && W && u && v && sigma2 && R && K && ws, "bad args (1..4 layers)");
+  SnBatch b{};
+  b.n = nlayers;
+  size_t tot_k = 0, tot_r = 0;
+  for (int i = 0; i < nlayers; ++i) { tot_k += K[i]; tot_r += R[i]; }
+  float* tp = ws;                                                // [t_0 .. t_n | s_0 .. s_n]: the t part is zeroed every call
+  float* sp = ws + tot_k;
+  for (int i = 0; i < nlayers; ++i) {
+    REQUIRE(W[i] && u[i] && v[i] && sigma2[i] && R[i] > 0 && K[i] > 0 && R[i] <= 4096, "bad layer %d", i);
+    b.W[i] = W[i]; b.u[i] = u[i]; b.v[i] = v[i]; b.sigma2[i] = sigma2[i];
+    b.us[i] = u_snap ? u_snap[i] : nullptr;
+    b.vs[i] = v_snap ? v_snap[i] : nullptr;
+    b.R[i] = R[i]; b.K[i] = K[i];
+    b.t[i] = tp; tp += K[i];
+    b.s[i] = sp; sp += R[i];
+  }
+  CHECK_HIP(tfc_launch_sn_step_batched(b, ws, tot_k * sizeof(float), power_iter, 1e-12f, (hipStream_t)stream), "tfc_spectral_norm_step_batched");
   return 0;
 }
 extern "C" int tfc_spectral_norm_bwd(void* stream, const float* G, const float* W, const float* u, const float* v, const float* sigma2,

@@ -109,7 +109,7 @@ tfc_act_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __re
 
 // backward. mode 0: dx = g' (no norm)   mode 1: rstats += (sum g', sum g'*xhat)   mode 2: dx = rstd*(g' - mg - xhat*mgx)
 //   g' = [blur^T](dropmask * dout) * act'(xhat);  xhat = norm ? (x-mean)*rstd : x;  use_x == 0 => act' = 1
-template <typename T, int MODE>
+template <typename T, int MODE, int POOL>
 __global__ void __launch_bounds__(256)
 tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats,
                    float* rstats, T* __restrict__ dx, int use_x, int dx_pitch) {
@@ -148,7 +148,7 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
       float g[UE];
 #pragma unroll
       for (int e = 0; e < UE; ++e) g[e] = 0.f;
-      if (p.pool == 0) {
+      if (POOL == 0) {
         unpack16<T>(*reinterpret_cast<const uint4*>(dn + (size_t)pix * p.o_pitch + cv * UE), g);
         if (p.drop_thresh24) {
           const uint32_t base = (uint32_t)(((size_t)n * nopix + pix) * p.C + cv * UE);
@@ -169,7 +169,7 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
           for (int e = 0; e < UE; ++e) g[e] += w * v[e];
         };
         const bool yin = y >= 2 && y <= p.H - 4, xin = xq >= 2 && xq <= p.W - 4;
-        if (p.pool == 2 && yin && xin) {
+        if (POOL == 2 && yin && xin) {
           // interior of a stride-2 BlurPool: exactly two outputs per dimension read this input, with taps {3/8, 1/8}
           const int oy0 = (y + 1) >> 1, ox0 = (xq + 1) >> 1;
           const float wy0 = (y & 1) ? 0.125f : 0.375f, wx0 = (xq & 1) ? 0.125f : 0.375f;
@@ -178,10 +178,16 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
           tap(oy0, ox0 - 1, wy0 * wx1);
           tap(oy0 - 1, ox0, wy1 * wx0);
           tap(oy0 - 1, ox0 - 1, wy1 * wx1);
+        } else if (POOL == 1 && yin && xin) {
+          // interior of the stride-1 blur: the 4x4 outputs (y+1-ky, x+1-kx) read this input with taps [1,3,3,1]^2/64
+#pragma unroll 1
+          for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) tap(y + 1 - ky, xq + 1 - kx, blur_w(ky) * blur_w(kx));
         } else {
-          // border (reflect-pad aliases) and stride-1 blur: enumerate (alias, tap) pairs; alias a: 0 -> p = y, 1 -> p = -1 (y == 1),
+          // border (reflect-pad aliases): enumerate (alias, tap) pairs; alias a: 0 -> p = y, 1 -> p = -1 (y == 1),
           // 2 -> p = n (y == n-2), 3 -> p = n+1 (y == n-3)
-          const int st = p.pool;
+          constexpr int st = POOL == 0 ? 1 : POOL;
           for (int ay = 0; ay < 4; ++ay) {
             if ((ay == 1 && y != 1) || (ay == 2 && y != p.H - 2) || (ay == 3 && y != p.H - 3)) continue;
             const int py = ay == 0 ? y : (ay == 1 ? -1 : (ay == 2 ? p.H : p.H + 1));
@@ -222,6 +228,10 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
 #pragma unroll
         for (int e = 0; e < UE; ++e) { a1[e] += g[e]; a2[e] += g[e] * xh[e]; }
       } else {
+        if (MODE == 0 && rstats) {
+#pragma unroll
+          for (int e = 0; e < UE; ++e) a1[e] += g[e];             // bias gradient of the convolution that produced x
+        }
         float r[UE];
 #pragma unroll
         for (int e = 0; e < UE; ++e) r[e] = (MODE == 2) ? rstd[e] * (g[e] - mg[e] - xh[e] * mgx[e]) : g[e];
@@ -240,6 +250,17 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
       for (int q = 0; q < PPB; ++q) { s1 += red[0][(q * CV + ccv) * UE + ce]; s2 += red[1][(q * CV + ccv) * UE + ce]; }
       atomicAdd(&rstats[((size_t)n * p.C + c) * 2 + 0], s1);
       atomicAdd(&rstats[((size_t)n * p.C + c) * 2 + 1], s2);
+    }
+  } else if (MODE == 0 && rstats) {                              // rstats = float[N][C]: per-image column sums of dx (bias gradient)
+#pragma unroll
+    for (int e = 0; e < UE; ++e) red[0][threadIdx.x * UE + e] = a1[e];
+    __syncthreads();
+    const int nch = CV * UE;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+      float s1 = 0.f;
+      const int ccv = c / UE, ce = c % UE;
+      for (int q = 0; q < PPB; ++q) s1 += red[0][(q * CV + ccv) * UE + ce];
+      atomicAdd(&rstats[(size_t)n * p.C + c], s1);
     }
   }
 }
@@ -320,29 +341,35 @@ __global__ void __launch_bounds__(256)
 tfc_tanh_bwd_pack_kernel(const float* __restrict__ g, const float* __restrict__ y, T* __restrict__ out, float* dbias,
                          int N, int C, int HW) {
   __shared__ float red[4][256];
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  float v[8];
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  const long long total = (long long)N * HW;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    float v[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) v[c] = 0.f;
-  if (idx < (long long)N * HW) {
+    for (int c = 0; c < 8; ++c) v[c] = 0.f;
     const int n = (int)(idx / HW), pix = (int)(idx - (long long)n * HW);
-    for (int c = 0; c < C; ++c) {
-      const size_t o = ((size_t)n * C + c) * HW + pix;
-      const float yy = y[o];
-      v[c] = g[o] * (1.f - yy * yy);
-    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) {
+        const size_t o = ((size_t)n * C + c) * HW + pix;
+        const float yy = y[o];
+        v[c] = g[o] * (1.f - yy * yy);
+        bs[c] += v[c];
+      }
     T* o = out + idx * 8;
     *reinterpret_cast<uint4*>(o) = pack16<T>(v);
     if (sizeof(T) == 4) *reinterpret_cast<uint4*>(o + 4) = pack16<T>(v + 4);
   }
-  if (dbias) {
-    for (int c = 0; c < C && c < 4; ++c) red[c][threadIdx.x] = v[c];
+  if (dbias) {                                                   // few workgroups => few same-address atomics (they serialise at ~12 ns each)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = bs[c];
     __syncthreads();
     if (threadIdx.x < 64) {
-      for (int c = 0; c < C && c < 4; ++c) {
-        float s = red[c][threadIdx.x] + red[c][threadIdx.x + 64] + red[c][threadIdx.x + 128] + red[c][threadIdx.x + 192];
-        s = wave_sum(s);
-        if (threadIdx.x == 0) atomicAdd(&dbias[c], s);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float sred = red[c][threadIdx.x] + red[c][threadIdx.x + 64] + red[c][threadIdx.x + 128] + red[c][threadIdx.x + 192];
+        sred = wave_sum(sred);
+        if (threadIdx.x == 0 && c < C) atomicAdd(&dbias[c], sred);
       }
     }
   }
@@ -399,6 +426,121 @@ __global__ void __launch_bounds__(1024) tfc_sn_sigma_kernel(const float* __restr
     sigma2[1] = 1.f / tot;
   }
 }
+// ---- batched form: all spectral-normed layers of one Discriminator1 forward in 3 launches (blockIdx.y = layer) ----
+struct SnBatch {
+  const float* W[4];
+  float* u[4]; float* v[4]; float* sigma2[4];
+  float* us[4]; float* vs[4];                                    // per-call snapshots of u, v for the backward (nullable)
+  float* s[4]; float* t[4];                                      // scratch
+  int R[4], K[4];
+  int n;
+};
+static __device__ TfcRedSlot g_sn_slot[4];
+
+__device__ __forceinline__ float block_sum_256(float a, float* red4) {
+  a = wave_sum(a);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = a;
+  __syncthreads();
+  return red4[0] + red4[1] + red4[2] + red4[3];
+}
+// s = W v (one wave per row)
+__global__ void __launch_bounds__(256) tfc_snb_mv_kernel(const SnBatch b) {
+  const int L = blockIdx.y, R = b.R[L], K = b.K[L];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* W = b.W[L] + (size_t)row * K;
+  const float* v = b.v[L];
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) a += W[k] * v[k];
+  a = wave_sum(a);
+  if (lane == 0) b.s[L][row] = a;
+}
+// u = s / max(|s|, eps) (norm recomputed per workgroup: R <= 512); t += W^T u over this workgroup's 32 rows
+__global__ void __launch_bounds__(256) tfc_snb_mtv_kernel(const SnBatch b, float eps) {
+  __shared__ float red4[4];
+  __shared__ float ush[32];
+  const int L = blockIdx.y, R = b.R[L], K = b.K[L];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.z * 32;
+  if (blockIdx.x * 256 >= K || r0 >= R) return;                  // workgroup-uniform
+  float a = 0.f;
+  for (int i = threadIdx.x; i < R; i += 256) { const float x = b.s[L][i]; a += x * x; }
+  const float inv = 1.f / fmaxf(sqrtf(block_sum_256(a, red4)), eps);
+  if (threadIdx.x < 32) {
+    const int r = r0 + threadIdx.x;
+    const float uv = r < R ? b.s[L][r] * inv : 0.f;
+    ush[threadIdx.x] = uv;
+    if (blockIdx.x == 0 && r < R) { b.u[L][r] = uv; if (b.us[L]) b.us[L][r] = uv; }
+  }
+  __syncthreads();
+  if (k >= K) return;
+  const float* W = b.W[L];
+  const int r1 = min(R, r0 + 32);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += W[(size_t)r * K + k] * ush[r - r0];
+  atomicAdd(&b.t[L][k], acc);
+}
+// v = t / max(|t|, eps) (when power_iter); sigma = u . (W v)
+__global__ void __launch_bounds__(256) tfc_snb_sigma_kernel(const SnBatch b, float eps, int power_iter) {
+  __shared__ float red4[4];
+  const int L = blockIdx.y, R = b.R[L], K = b.K[L];
+  const int nblk = (R + 3) / 4;
+  if ((int)blockIdx.x >= nblk) return;
+  float inv = 1.f;
+  const float* vin = power_iter ? b.t[L] : b.v[L];
+  if (power_iter) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) { const float x = vin[i]; a += x * x; }
+    inv = 1.f / fmaxf(sqrtf(block_sum_256(a, red4)), eps);
+    if (blockIdx.x == 0)
+      for (int i = threadIdx.x; i < K; i += 256) { const float x = vin[i] * inv; b.v[L][i] = x; if (b.vs[L]) b.vs[L][i] = x; }
+  } else if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < K; i += 256) if (b.vs[L]) b.vs[L][i] = vin[i];
+    for (int i = threadIdx.x; i < R; i += 256) if (b.us[L]) b.us[L][i] = b.u[L][i];
+  }
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float part = 0.f;
+  if (row < R) {
+    const float* W = b.W[L] + (size_t)row * K;
+    float a = 0.f;
+    for (int k = lane; k < K; k += 64) a += W[k] * vin[k];
+    a = wave_sum(a) * inv;
+    // u of this row: written by the mtv kernel of this call (power_iter) or the stored buffer
+    part = a * b.u[L][row];
+  }
+  __syncthreads();
+  if (lane == 0) red4[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    TfcRedSlot* slot = &g_sn_slot[L];
+    atomicAdd(&slot->acc, (double)red4[0] + (double)red4[1] + (double)red4[2] + (double)red4[3]);
+    __threadfence();
+    const unsigned tk = atomicAdd(&slot->cnt, 1u);
+    if (tk == (unsigned)nblk - 1) {
+      __threadfence();
+      const double tot = atomicAdd(&slot->acc, 0.0);
+      atomicExch(reinterpret_cast<unsigned long long*>(&slot->acc), 0ull);
+      atomicExch(&slot->cnt, 0u);
+      b.sigma2[L][0] = (float)tot;
+      b.sigma2[L][1] = (float)(1.0 / tot);
+    }
+  }
+}
+
+hipError_t tfc_launch_sn_step_batched(const SnBatch& b, float* ws_t, size_t t_bytes, int power_iter, float eps, hipStream_t st) {
+  int maxR = 0, maxK = 0;
+  for (int i = 0; i < b.n; ++i) { maxR = b.R[i] > maxR ? b.R[i] : maxR; maxK = b.K[i] > maxK ? b.K[i] : maxK; }
+  if (power_iter) {
+    hipLaunchKernelGGL(tfc_snb_mv_kernel, dim3((maxR + 3) / 4, b.n), dim3(256), 0, st, b);
+    hipError_t e = hipMemsetAsync(ws_t, 0, t_bytes, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tfc_snb_mtv_kernel, dim3((maxK + 255) / 256, b.n, (maxR + 31) / 32), dim3(256), 0, st, b, eps);
+  }
+  hipLaunchKernelGGL(tfc_snb_sigma_kernel, dim3((maxR + 3) / 4, b.n), dim3(256), 0, st, b, eps, power_iter);
+  return hipGetLastError();
+}
+
 // spectral-norm backward: gw = (G - (sum G*Wsn) u v^T) / sigma, Wsn = W/sigma.  pass 1: dot += sum G*W ; pass 2: apply
 __global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* out) {
   __shared__ float red[4];
@@ -516,16 +658,23 @@ static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stat
 hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st) {
   return dt == TFC_DT_BF16 ? act_fwd_t<bf16_t>(p, x, stats, out, stats_out, st) : act_fwd_t<float>(p, x, stats, out, stats_out, st);
 }
+template <typename T, int MODE>
+static void act_bwd_launch(const dim3& grid, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats,
+                           void* dx, int use_x, int dx_pitch, hipStream_t st) {
+  if (p.pool == 0)
+    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, MODE, 0>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
+  else if (p.pool == 1)
+    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, MODE, 1>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
+  else
+    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, MODE, 2>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
+}
 template <typename T>
 static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats,
                             void* dx, int use_x, int dx_pitch, hipStream_t st) {
   const dim3 grid = act_grid(p.H * p.W, p.C, ElemTraits<T>::UE, p.N);
-  if (mode == 0)
-    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, 0>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
-  else if (mode == 1)
-    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, 1>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
-  else
-    hipLaunchKernelGGL((tfc_act_bwd_kernel<T, 2>), grid, dim3(256), 0, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, use_x, dx_pitch);
+  if (mode == 0) act_bwd_launch<T, 0>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
+  else if (mode == 1) act_bwd_launch<T, 1>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
+  else act_bwd_launch<T, 2>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
   return hipGetLastError();
 }
 hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats,
@@ -558,7 +707,9 @@ hipError_t tfc_launch_unpack_nchw(int dt, const void* in, int pitch, int c0, int
 }
 hipError_t tfc_launch_tanh_bwd_pack(int dt, const float* g, const float* y, void* out, float* dbias, int N, int C, int HW, hipStream_t st) {
   const long long tot = (long long)N * HW;
-  const dim3 grid((unsigned)((tot + 255) / 256));
+  long long nbk = (tot + 255) / 256;
+  if (nbk > 1024) nbk = 1024;
+  const dim3 grid((unsigned)nbk);
   if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<bf16_t>), grid, dim3(256), 0, st, g, y, (bf16_t*)out, dbias, N, C, HW);
   else hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<float>), grid, dim3(256), 0, st, g, y, (float*)out, dbias, N, C, HW);
   return hipGetLastError();

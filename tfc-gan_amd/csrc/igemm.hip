@@ -345,7 +345,10 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 // ---------------------------------------------------------------------------------------------------
 template <typename T> struct WgradFrag;
 
-template <typename T, int TPW>
+//   RASTER (bf16, 16 taps in 4x4 raster order): wave w owns filter COLUMN kx = w (taps ky*4 + w). The B fragment of (k-step kt,
+//   filter row ky) is the halo row kt + ky at column shift w, i.e. it only depends on kt + ky: a 4-deep sliding register
+//   window needs ONE new fragment per k-step instead of four.
+template <typename T, int TPW, bool RASTER>
 __global__ void __launch_bounds__(256, 2)
 tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restrict__ in, float* dwacc,
                  int Nn_pad, int Nn_real, int Cw_real, int nbw, int ncb, int nsplit) {
@@ -438,7 +441,38 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
   auto compute = [&](const unsigned char* buf) {
     const unsigned char* dob = buf;
     const unsigned char* hab = buf + DO_BYTES;
-    if constexpr (ES == 2) {
+    if constexpr (ES == 2 && RASTER) {
+      auto tr16 = [&](const unsigned char* p0) {
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + 4 * ROWB));
+        uint4 r;
+        r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+        r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+        r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+        r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+        return r;
+      };
+      const unsigned char* hcol = hab + wave * ROWB + trLane;     // halo column shift kx = wave
+      const int rowb = pd.hw * ROWB;
+      uint4 bw[4];
+      bw[0] = tr16(hcol);
+      bw[1] = tr16(hcol + rowb);
+      bw[2] = tr16(hcol + 2 * rowb);
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        bw[(kt + 3) & 3] = tr16(hcol + (kt + 3) * rowb);
+        uint4 a[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) a[ni] = tr16(dob + ni * 128 * ROWB + kt * 16 * ROWB + trLane);
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            if (ni < nni)
+              acc[ky][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ni]),
+                                                                     __builtin_bit_cast(bf16x8_t, bw[(kt + ky) & 3]), acc[ky][ni], 0, 0, 0);
+      }
+    } else if constexpr (ES == 2) {
 #pragma unroll 2
       for (int kt = 0; kt < 8; ++kt) {
         uint4 a[2];
@@ -714,9 +748,12 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   const int lds = (2 * 128 * 32 * ES + TFC_MAX_HH * TFC_MAX_HW * 32 * ES) * (ES == 2 ? 2 : 1);
   const dim3 grid(nbw * ncb * nsplit);
   const int tpw = (d.plane[0].ntaps + 3) / 4;                    // taps per wave (tap t belongs to wave t % 4)
-#define TFC_WG(TPW_) hipLaunchKernelGGL((tfc_wgrad_kernel<T, TPW_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, \
-                                        Nn_pad, Nn_real, Cw_real, nbw, ncb, nsplit)
-  if (tpw <= 1) TFC_WG(1); else if (tpw == 2) TFC_WG(2); else if (tpw == 3) TFC_WG(3); else TFC_WG(4);
+  bool raster = (ES == 2) && d.plane[0].ntaps == 16;
+  for (int t = 0; t < 16 && raster; ++t) raster = d.plane[0].tap_dy[t] == (t >> 2) && d.plane[0].tap_dx[t] == (t & 3);
+#define TFC_WG(TPW_, R_) hipLaunchKernelGGL((tfc_wgrad_kernel<T, TPW_, R_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, \
+                                            Nn_pad, Nn_real, Cw_real, nbw, ncb, nsplit)
+  if (raster) TFC_WG(4, true);
+  else if (tpw <= 1) TFC_WG(1, false); else if (tpw == 2) TFC_WG(2, false); else if (tpw == 3) TFC_WG(3, false); else TFC_WG(4, false);
 #undef TFC_WG
   return hipGetLastError();
 }

@@ -149,7 +149,7 @@ hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int*
   if (e != hipSuccess) return e;
   long long nrows = (long long)N * C * 1024;
   long long nb = (nrows + 3) / 4;
-  if (nb > 8192) nb = 8192;
+  if (nb > 512) nb = 512;                                        // one double atomic + one ticket per workgroup on a single address
   hipLaunchKernelGGL(tfc_triplet16_kernel, dim3((int)nb), dim3(256), 0, st, fake, real, ni, N, C, margin, eps, loss, dfake, gscale);
   return hipGetLastError();
 }
@@ -178,7 +178,7 @@ hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int
 }
 hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st) {
   long long nb = (n + 255) / 256;
-  if (nb > 2048) nb = 2048;
+  if (nb > 512) nb = 512;
   hipLaunchKernelGGL(tfc_l1_sum_kernel, dim3((int)nb), dim3(256), 0, st, a, b, n, scale, out);
   return hipGetLastError();
 }

@@ -260,12 +260,24 @@ class DiscriminatorCore:
         x8 = ops.pack_nhwc8(dt, img_a, img_b)
         ctx.ins, ctx.raw, ctx.sn = [], [], []
         cur = x8
-        for i, cin, cout in D_BLOCKS:
-            W = self.params[f"model.{i}.parametrizations.weight.original"]
-            u = self.buffers[f"model.{i}.parametrizations.weight.0._u"]
-            v = self.buffers[f"model.{i}.parametrizations.weight.0._v"]
-            sigma2 = torch.empty(2, dtype=torch.float32, device=dev)
-            ops.spectral_norm_step(W, u, v, sigma2, power_iter=power_iter)
+        # spectral norm of all four blocks in one batched power iteration; per-call snapshots of u, v, sigma for the backward
+        Ws = [self.params[f"model.{i}.parametrizations.weight.original"] for i, _, _ in D_BLOCKS]
+        us = [self.buffers[f"model.{i}.parametrizations.weight.0._u"] for i, _, _ in D_BLOCKS]
+        vs = [self.buffers[f"model.{i}.parametrizations.weight.0._v"] for i, _, _ in D_BLOCKS]
+        nu, nv = [u.numel() for u in us], [v.numel() for v in vs]
+        snap = torch.empty(sum(nu) + sum(nv) + 2 * len(Ws), dtype=torch.float32, device=dev)
+        offs, o = [], 0
+        for a in nu + nv + [2] * len(Ws):
+            offs.append(o)
+            o += a
+        L = len(Ws)
+        usn = [snap[offs[k]:offs[k] + nu[k]] for k in range(L)]
+        vsn = [snap[offs[L + k]:offs[L + k] + nv[k]] for k in range(L)]
+        sig = [snap[offs[2 * L + k]:offs[2 * L + k] + 2] for k in range(L)]
+        self._sn_ws = ops.spectral_norm_step_batched(Ws, us, vs, sig, power_iter=power_iter, u_snaps=usn if save else None,
+                                                     v_snaps=vsn if save else None, ws=getattr(self, "_sn_ws", None))
+        for bi, (i, cin, cout) in enumerate(D_BLOCKS):
+            sigma2 = sig[bi]
             h = cur.H
             raw = new_act(N, h - 1, h - 1, cout, dt, dev)
             ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:])
@@ -273,7 +285,7 @@ class DiscriminatorCore:
             ops.act_fwd(dt, raw, out, stats=None, slope=0.2, pool=2)
             ctx.ins.append(cur)
             ctx.raw.append(raw)
-            ctx.sn.append((u.clone(), v.clone(), sigma2) if save else None)
+            ctx.sn.append((usn[bi], vsn[bi], sigma2) if save else None)
             cur = out
         logits = new_act(N, cur.H, cur.W, 8, dt, dev, zero=True)
         ops.conv_fwd(dt, OP_PADCONV, cur, 512, 1, self.head_packed["fwd"], View(logits.t, 1, 0))
@@ -299,13 +311,14 @@ class DiscriminatorCore:
             u, v, sigma2 = ctx.sn[bi]
             Hc = raw.H
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
-            ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2)
+            gb_img = torch.zeros((N, cout), dtype=torch.float32, device=dev) if grads is not None else None
+            ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
             W = self.params[f"model.{i}.parametrizations.weight.original"]
             if grads is not None:
                 gbias = grads[f"model.{i}.bias"]
                 if not accumulate:
                     gbias.zero_()
-                ops.colsum(dt, d_raw, gbias)
+                ops.colsum(ops.DT_F32, View(gb_img.view(N, 1, 1, cout), cout), gbias)
                 gsn = torch.empty_like(W)
                 ws = ops.conv_wgrad(dt, OP_CONV, xin, d_raw, cin, cout, gsn, False, ws)
                 ops.spectral_norm_bwd(gsn, W, u, v, sigma2, grads[f"model.{i}.parametrizations.weight.original"], accumulate)

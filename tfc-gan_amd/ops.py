@@ -210,6 +210,23 @@ def spectral_norm_step(W, u, v, sigma2, power_iter=True, ws=None):
           "tfc_spectral_norm_step")
 
 
+def spectral_norm_step_batched(Ws, us, vs, sigma2s, power_iter=True, u_snaps=None, v_snaps=None, ws=None):
+    """one power iteration (u <- norm(W v), v <- norm(W^T u), sigma = u.W v) for up to 4 layers in 3 launches"""
+    n = len(Ws)
+    R = [int(W.shape[0]) for W in Ws]
+    K = [int(W.numel() // W.shape[0]) for W in Ws]
+    Ra, Ka = (ctypes.c_int * n)(*R), (ctypes.c_int * n)(*K)
+    need = lib().tfc_spectral_norm_batched_ws_floats(n, Ra, Ka)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=Ws[0].device)
+
+    def arr(ts):
+        return None if ts is None else (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    check(lib().tfc_spectral_norm_step_batched(stream_ptr(), n, arr(Ws), arr(us), arr(vs), arr(sigma2s), arr(u_snaps), arr(v_snaps),
+                                               Ra, Ka, _p(ws), 1 if power_iter else 0), "tfc_spectral_norm_step_batched")
+    return ws
+
+
 def spectral_norm_bwd(G, W, u, v, sigma2, gout, accumulate=False):
     R = W.shape[0]
     K = W.numel() // R
