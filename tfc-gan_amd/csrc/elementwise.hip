@@ -107,6 +107,87 @@ tfc_act_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __re
   }
 }
 
+// Stride-2 BlurPool forward, separable and blocked: a thread produces a 2x2 block of outputs from its 6x6 input window --
+// 36 loads / activations per 4 outputs instead of 64 -- horizontal [1,3,3,1]/8 pass per input row, then the vertical pass.
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_act_pool2_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ out) {
+  constexpr int UE = ElemTraits<T>::UE;
+  const int CV = p.C / UE;
+  const int PPB = 256 / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  const int n = blockIdx.y;
+  const int bw = (p.Wo + 1) >> 1, bh = (p.Ho + 1) >> 1;
+  const int nob = bw * bh;
+  const int npix = p.Ho * p.Wo;
+  float mean[UE], rstd[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) { mean[e] = 0.f; rstd[e] = 1.f; }
+  if (p.norm) {
+    const float inv = 1.f / (float)(p.H * p.W);
+#pragma unroll
+    for (int e = 0; e < UE; ++e) {
+      const float s1 = stats[((size_t)n * p.C + cv * UE + e) * 2 + 0];
+      const float s2 = stats[((size_t)n * p.C + cv * UE + e) * 2 + 1];
+      const float m = s1 * inv;
+      mean[e] = m;
+      rstd[e] = rsqrtf(fmaxf(s2 * inv - m * m, 0.f) + p.eps);
+    }
+  }
+  const T* xn = x + (size_t)n * p.H * p.W * p.x_pitch;
+  T* on = out + (size_t)n * npix * p.o_pitch;
+  if (pl >= PPB) return;
+  for (int ob = blockIdx.x * PPB + pl; ob < nob; ob += gridDim.x * PPB) {
+    const int oby = ob / bw, obx = ob - oby * bw;
+    int cx[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) cx[j] = min(max(reflect_idx(4 * obx - 1 + j, p.W), 0), p.W - 1);
+    float o00[UE], o01[UE], o10[UE], o11[UE];
+#pragma unroll
+    for (int e = 0; e < UE; ++e) { o00[e] = 0.f; o01[e] = 0.f; o10[e] = 0.f; o11[e] = 0.f; }
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {                                // one input row at a time: 6 loads in flight, not 36
+      const int yy = min(max(reflect_idx(4 * oby - 1 + i, p.H), 0), p.H - 1);
+      const T* row = xn + (size_t)yy * p.W * p.x_pitch + cv * UE;
+      float h0[UE], h1[UE];
+#pragma unroll
+      for (int e = 0; e < UE; ++e) { h0[e] = 0.f; h1[e] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        float v[UE];
+        unpack16<T>(*reinterpret_cast<const uint4*>(row + (size_t)cx[j] * p.x_pitch), v);
+#pragma unroll
+        for (int e = 0; e < UE; ++e) {
+          float t = p.norm ? (v[e] - mean[e]) * rstd[e] : v[e];
+          t = t > 0.f ? t : t * p.slope;
+          if (j < 4) h0[e] += blur_w(j) * t;
+          if (j >= 2) h1[e] += blur_w(j - 2) * t;
+        }
+      }
+      const float wa = i < 4 ? blur_w(i) : 0.f, wb = i >= 2 ? blur_w(i - 2) : 0.f;
+#pragma unroll
+      for (int e = 0; e < UE; ++e) {
+        o00[e] += wa * h0[e]; o01[e] += wa * h1[e];
+        o10[e] += wb * h0[e]; o11[e] += wb * h1[e];
+      }
+    }
+    auto store = [&](int oy, int ox, float* r) {
+      if (oy >= p.Ho || ox >= p.Wo) return;
+      const int pix = oy * p.Wo + ox;
+      if (p.drop_thresh24) {
+        const uint32_t base = (uint32_t)(((size_t)n * npix + pix) * p.C + cv * UE);
+#pragma unroll
+        for (int e = 0; e < UE; ++e) r[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? r[e] * p.drop_scale : 0.f;
+      }
+      *reinterpret_cast<uint4*>(on + (size_t)pix * p.o_pitch + cv * UE) = pack16<T>(r);
+    };
+    store(2 * oby, 2 * obx, o00);
+    store(2 * oby, 2 * obx + 1, o01);
+    store(2 * oby + 1, 2 * obx, o10);
+    store(2 * oby + 1, 2 * obx + 1, o11);
+  }
+}
+
 // backward. mode 0: dx = g' (no norm)   mode 1: rstats += (sum g', sum g'*xhat)   mode 2: dx = rstd*(g' - mg - xhat*mgx)
 //   g' = [blur^T](dropmask * dout) * act'(xhat);  xhat = norm ? (x-mean)*rstd : x;  use_x == 0 => act' = 1
 template <typename T, int MODE, int POOL>
@@ -648,6 +729,11 @@ static inline dim3 act_grid(int npix, int C, int ue, int N) {
 
 template <typename T>
 static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st) {
+  if (p.pool == 2 && !stats_out) {
+    const dim3 g2 = act_grid(((p.Ho + 1) / 2) * ((p.Wo + 1) / 2), p.C, ElemTraits<T>::UE, p.N);
+    hipLaunchKernelGGL((tfc_act_pool2_fwd_kernel<T>), g2, dim3(256), 0, st, p, (const T*)x, stats, (T*)out);
+    return hipGetLastError();
+  }
   const dim3 grid = act_grid(p.Ho * p.Wo, p.C, ElemTraits<T>::UE, p.N);
   if (stats_out)
     hipLaunchKernelGGL((tfc_act_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)x, stats, (T*)out, stats_out);
