@@ -54,6 +54,10 @@ int tfc_conv_pack(void* stream, int dt, int op, int pass, const float* w, const 
  * discriminator's operand streams are packed once per weight update and not once per forward. */
 int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
                  const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags);
+/* ---- PatchGAN head forward, P16:201-202: ZeroPad2d((1,0,1,0)) + Conv2d(C,1,k4,p1,no bias) as a wave-per-pixel dot product
+ * (w: torch-layout fp32 [1][C][4][4], y: [N][H][W][y_pitch] channel 0). Same result as tfc_conv_fwd(TFC_OP_PADCONV, Cout=1). */
+int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* w,
+                          void* y, int y_pitch);
 /* ---- input gradient: dx = oscale * op^T(dy) (flags: TFC_EP_ACCUM) ------------------------------------------------ */
 int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
                    const void* packed, void* dx, int dx_pitch, const float* oscale, int flags);

@@ -139,6 +139,17 @@ def test_conv_family(op, N, H, W, Cin, Cout, dt, cfg, force_cfg):
     assert (dw.cpu() - 2 * gw).abs().max().item() <= 2 * wtol
 
 
+def test_patchgan_head_kernel_matches_padconv():
+    for dt in (DT_F32, DT_BF16):
+        x = q(rnd((2, 512, 16, 16), 21), dt)
+        w = rnd((1, 512, 4, 4), 22, 0.02)
+        want = ref_conv(ops.OP_PADCONV, x, w if dt == DT_F32 else w)          # the head kernel reads the fp32 weights directly
+        yv = ops.new_act(2, 16, 16, 8, dt, DEV, zero=True)
+        ops.patchgan_head_fwd(dt, to_view(x, dt), w.to(DEV), View(yv.t, 1))
+        got = from_view(View(yv.t, 1))
+        assert (got - want).abs().max().item() <= (2e-5 if dt == DT_F32 else 1e-2) * want.abs().max().item()
+
+
 def test_upconv_tanh_nchw_head():
     """generator head: Upsample + ZeroPad + Conv + Tanh written as fp32 NCHW (P16:153-158)"""
     for dt in (DT_F32, DT_BF16):

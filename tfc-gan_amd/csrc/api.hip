@@ -45,6 +45,7 @@ hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int*
 hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img, int nwin, float* amp, float* pha, int shift, hipStream_t st);
 hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st);
 hipError_t tfc_launch_probe(float* out, hipStream_t st);
+hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st);
 struct SnBatch {
   const float* W[4];
   float* u[4]; float* v[4]; float* sigma2[4];
@@ -157,6 +158,7 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
   d.out_pitch = out_pitch;
   d.SS = 1; d.OS = 1; d.OOY = 0; d.OOX = 0;
   d.nplanes = 1;
+  d.ph_n = 1; d.ph_d0 = 0; d.ph_oo = 0;
   const int py = phase >> 1, px = phase & 1;
   const bool fwd_geom = (pass != 1);
   if (fwd_geom) {
@@ -349,11 +351,14 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
   }
   if (flags & TFC_EP_BIAS) REQUIRE(bias != nullptr, "bias is null");
   if (flags & TFC_EP_STATS) REQUIRE(stats != nullptr, "stats is null");
-  const int nph = num_phases(op, 0);
+  int nph = num_phases(op, 0);
+  const bool fold = (op == TFC_OP_CONVT);                        // equal-shaped phases: fold all four into the grid of one launch
+  if (fold) nph = 1;
   ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
   for (int ph = 0; ph < nph; ++ph) {
     TfcGather d;
     if (int e = build_desc(op, 0, ph, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, nullptr)) return e;
+    if (fold) { d.ph_n = 4; d.ph_d0 = 1; d.ph_oo = 1; }          // phase 0 descriptor + per-phase shifts (dy0 = py-1, OOY = py)
     if (int e = check_desc(d, dt)) return e;
     CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
   }
@@ -374,6 +379,16 @@ extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int 
   if (int e = check_desc(d, dt)) return e;
   ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
   CHECK_HIP(tfc_launch_igemm(dt, d, dy, packed, dx, nullptr, nullptr, nullptr, oscale, flags, (hipStream_t)stream), "tfc_conv_dgrad");
+  return 0;
+}
+
+extern "C" int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* w,
+                                     void* y, int y_pitch) {
+  REQUIRE(dt == TFC_DT_BF16 || dt == TFC_DT_F32, "bad dtype");
+  if (int e = check_ptr16(x, "x")) return e;
+  const int ue = 16 / es_of(dt);
+  REQUIRE(w && y && N > 0 && H > 0 && W > 0 && C > 0 && C % ue == 0 && C <= 2048 && x_pitch >= C && x_pitch % ue == 0 && y_pitch >= 1, "bad args");
+  CHECK_HIP(tfc_launch_head_fwd(dt, x, x_pitch, w, y, y_pitch, N, H, W, C, (hipStream_t)stream), "tfc_patchgan_head_fwd");
   return 0;
 }
 

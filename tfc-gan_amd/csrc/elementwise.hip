@@ -715,6 +715,48 @@ __global__ void __launch_bounds__(256) tfc_cast_to_f32_kernel(const T* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
+// PatchGAN head forward: ZeroPad2d((1,0,1,0)) + Conv2d(C -> 1, k4, p1, no bias)   (reference :201-202).
+// One output channel is a poor fit for an MFMA tile (N = 1 of 32) and, at 16x16 outputs, for the tile grid (64 workgroups
+// x 512 serial k-steps): here a wave owns one output pixel, lanes split the C channels (16 B each), the 16 taps are walked
+// with the filter held transposed in LDS, and a wave shuffle finishes the dot product.
+// y[n][oy][ox] = sum_{ky,kx,c} x[n][oy+ky-2][ox+kx-2][c] * w[c][ky][kx]
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_head_fwd_kernel(const T* __restrict__ x, int x_pitch, const float* __restrict__ w, T* __restrict__ y, int y_pitch,
+                    int N, int H, int W, int C) {
+  constexpr int UE = ElemTraits<T>::UE;
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // [16 taps][C]
+  for (int i = threadIdx.x; i < 16 * C; i += 256) {
+    const int c = i >> 4, t = i & 15;                             // torch layout index c*16 + t
+    wl[t * C + c] = w[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npix = N * H * W;
+  const int CV = C / UE;                                          // 16-byte units per pixel
+  for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
+    const int n = pix / (H * W), rem = pix - n * H * W;
+    const int oy = rem / W, ox = rem - oy * W;
+    float acc = 0.f;
+    for (int t = 0; t < 16; ++t) {
+      const int iy = oy + (t >> 2) - 2, ix = ox + (t & 3) - 2;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;       // wave-uniform
+      const T* px = x + ((size_t)(n * H + iy) * W + ix) * x_pitch;
+      for (int u = lane; u < CV; u += 64) {
+        float v[UE];
+        unpack16<T>(*reinterpret_cast<const uint4*>(px + u * UE), v);
+        const float* wt = wl + t * C + u * UE;
+#pragma unroll
+        for (int e = 0; e < UE; ++e) acc += v[e] * wt[e];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) ElemTraits<T>::st(y + (size_t)pix * y_pitch, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
 static inline dim3 act_grid(int npix, int C, int ue, int N) {
@@ -867,5 +909,15 @@ hipError_t tfc_launch_cast(int dt, int to_f32, const void* x, void* y, long long
     if (to_f32) hipLaunchKernelGGL((tfc_cast_to_f32_kernel<float>), dim3((int)nb), dim3(256), 0, st, (const float*)x, (float*)y, n);
     else hipLaunchKernelGGL((tfc_cast_from_f32_kernel<float>), dim3((int)nb), dim3(256), 0, st, (const float*)x, (float*)y, n);
   }
+  return hipGetLastError();
+}
+
+hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st) {
+  const int npix = N * H * W;
+  int nb = (npix + 3) / 4;
+  if (nb > 1024) nb = 1024;
+  const size_t lds = (size_t)16 * C * sizeof(float);
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_head_fwd_kernel<bf16_t>), dim3(nb), dim3(256), lds, st, (const bf16_t*)x, x_pitch, w, (bf16_t*)y, y_pitch, N, H, W, C);
+  else hipLaunchKernelGGL((tfc_head_fwd_kernel<float>), dim3(nb), dim3(256), lds, st, (const float*)x, x_pitch, w, (float*)y, y_pitch, N, H, W, C);
   return hipGetLastError();
 }

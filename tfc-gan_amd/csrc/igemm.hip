@@ -72,7 +72,7 @@ template <typename T, int MT, int NT, int WM, int WN, int PAT>
 __global__ void __launch_bounds__(256, 3)
 tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __restrict__ wp, T* out,
                  const float* __restrict__ bias, float* stats, float* out_nchw, const float* __restrict__ oscale,
-                 int flags, int NB32, int nblkN, int buf_bytes, int total_sub) {
+                 int flags, int NB32, int nblkN, int buf_bytes, long long phase_wbytes) {
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WM * MT == 4, "tile is 4 M-subtiles (128 pixels)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,8 +99,10 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   const int nb_blk = bid % nblkN;
   int tile = bid / nblkN;
   const int txb = tile % d.tiles_x; tile /= d.tiles_x;
-  const int tyb = tile % d.tiles_y;
-  const int img = tile / d.tiles_y;
+  const int tyb = tile % d.tiles_y; tile /= d.tiles_y;
+  const int img = tile % d.nimg;
+  const int phase = tile / d.nimg;                              // sub-pixel phase folded into the grid (transposed conv)
+  const int phy = phase >> 1, phx = phase & 1;
   const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
   const int nb0 = (nb_blk * WN + wn) * NT;                     // first 32-channel block of this wave
 
@@ -133,8 +135,8 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         const int pix = idx >> upp_shift, g = idx & (UPP - 1);
         const int hy = pix / pd.hw, hx = pix - hy * pd.hw;
         hoff[i] = (hy * P + hx) * PS + g * 16;
-        const int y = (a0 + pd.dy0 + hy) * d.SS + pd.py;
-        const int x = (b0 + pd.dx0 + hx) * d.SS + pd.px;
+        const int y = (a0 + pd.dy0 + phy * d.ph_d0 + hy) * d.SS + pd.py;
+        const int x = (b0 + pd.dx0 + phx * d.ph_d0 + hx) * d.SS + pd.px;
         if (y >= 0 && y < d.IH && x >= 0 && x < d.IW)
           hv[i] = *reinterpret_cast<const uint4*>(in_img + ((size_t)(y * d.IW + x)) * d.in_pitch + cc * CK + g * UE);
       }
@@ -148,7 +150,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 
   // ---- weight stream: wave-uniform base (scalar registers) + constant per-lane offset; the stream carries TFC_WPAD
   //      k-substeps of slack after its last real one, so the prefetch never needs a bounds check ----
-  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wp);
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(wp) + (size_t)phase * (size_t)phase_wbytes;
   const unsigned laneoff = (unsigned)(nb0 * 64 + lane) * 16u;
   const size_t wstep_b = (size_t)NB32 * 1024;
   auto loadB = [&](int gs, uint4 (&b)[NT]) {
@@ -274,7 +276,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
           if (ok) { s1 += v; s2 += v * v; }
           *reinterpret_cast<bf16_t*>(smem + (ty * TFC_TILE_W + tx) * ROWP + ((wn * NT + nt) * 32 + r) * 2) = f32_to_bf16(v);
         } else if (ok) {
-          const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+          const int oy = a * d.OS + d.OOY + phy * d.ph_oo, ox = b * d.OS + d.OOX + phx * d.ph_oo;
           if (flags & TFC_EP_TANH_NCHW) {
             out_nchw[(((size_t)img * d.Nout + n) * d.OH + oy) * d.OW + ox] = tanhf(v);
           } else {
@@ -306,7 +308,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
       const int a = a0 + ty, b = b0 + tx;
       const int n0 = nbase + u * 8;
       if (a < d.GH && b < d.GW && n0 < d.Nout) {
-        const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+        const int oy = a * d.OS + d.OOY + phy * d.ph_oo, ox = b * d.OS + d.OOX + phx * d.ph_oo;
         T* po = out + ((size_t)(img * d.OH + oy) * d.OW + ox) * d.out_pitch + n0;
         uint4 v = *reinterpret_cast<const uint4*>(smem + pix * ROWP + u * 16);
         if (n0 + 8 <= d.Nout) {
@@ -687,10 +689,10 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
     const int ep = 128 * (32 * NT * WN * ES + 16);
     lds = lds > ep ? lds : ep;
   }
-  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
-  const int total_sub = tfc_total_substeps(d, ES);
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1);
+  const long long phase_wbytes = (long long)tfc_packed_bytes(d, ES);
   hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
-                     (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, total_sub);
+                     (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes);
   return hipGetLastError();
 }
 

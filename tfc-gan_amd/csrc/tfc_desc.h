@@ -54,6 +54,8 @@ struct TfcGather {
   int nplanes;
   int OH, OW, OS, OOY, OOX;   // output tensor dims, output stride / offset (sub-pixel phases)
   int out_pitch, Nout;        // output pixel pitch (elements), real output channels
+  int ph_n;                   // sub-pixel phases folded into ONE launch (1 or 4): phase (py,px) = (ph >> 1, ph & 1)
+  int ph_d0, ph_oo;           // per phase bit: shift of the halo origin (dy0/dx0) and of the output offset (OOY/OOX)
   struct TfcPlane plane[TFC_MAX_PLANES];
 };
 

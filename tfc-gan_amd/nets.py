@@ -288,7 +288,7 @@ class DiscriminatorCore:
             ctx.sn.append((usn[bi], vsn[bi], sigma2) if save else None)
             cur = out
         logits = new_act(N, cur.H, cur.W, 8, dt, dev, zero=True)
-        ops.conv_fwd(dt, OP_PADCONV, cur, 512, 1, self.head_packed["fwd"], View(logits.t, 1, 0))
+        ops.patchgan_head_fwd(dt, cur, self.params["model.13.weight"], View(logits.t, 1, 0))
         ctx.p4 = cur
         return View(logits.t, 1, 0), (ctx if save else None)
 

@@ -115,6 +115,10 @@ def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stat
           "tfc_conv_fwd")
 
 
+def patchgan_head_fwd(dt, x: View, w, y: View):
+    check(lib().tfc_patchgan_head_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, x.C, _p(w), y.ptr, y.pitch), "tfc_patchgan_head_fwd")
+
+
 def conv_dgrad(dt, op, dy: View, N, H, W, Cin, Cout, packed, dx: View, accumulate=False, oscale=None):
     check(lib().tfc_conv_dgrad(stream_ptr(), dt, op, dy.ptr, dy.pitch, N, H, W, Cin, Cout, _p(packed), dx.ptr, dx.pitch,
                                _p(oscale), EP_ACCUM if accumulate else 0), "tfc_conv_dgrad")
