@@ -49,6 +49,13 @@ int tfc_abi_version(void);
 size_t tfc_conv_packed_bytes(int dt, int op, int pass, int Cin, int Cout);
 int tfc_conv_pack(void* stream, int dt, int op, int pass, const float* w, const float* scale, void* packed, int Cin, int Cout);
 
+/* Planned packing: all operand streams of a network in ONE launch. Build the job table once on the host (geometry, weight and
+ * stream pointers are fixed for the lifetime of an engine), copy it to the device, then call tfc_conv_pack_planned per update. */
+size_t tfc_pack_plan_bytes(int nlayers);
+int tfc_pack_plan_build(int dt, int nlayers, const int* ops_host, const int* passes_host, const float* const* w_host,
+                        void* const* packed_host, const int* Cin_host, const int* Cout_host, void* plan_host, int* nblocks_host);
+int tfc_conv_pack_planned(void* stream, int dt, const void* plan_dev, int njobs, int nblocks);
+
 /* ---- forward: y = oscale * op(x) + bias ; x: [N][H][W][x_pitch], y: [N][OH][OW][y_pitch] (OH = H-1 | H | 2H | 2H) ---
  * oscale: nullable DEVICE scalar multiplying the accumulator before the bias -- 1/sigma of spectral_norm (P16:188), so the
  * discriminator's operand streams are packed once per weight update and not once per forward. */
@@ -61,7 +68,8 @@ int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int 
 /* ---- input gradient: dx = oscale * op^T(dy) (flags: TFC_EP_ACCUM) ------------------------------------------------ */
 int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
                    const void* packed, void* dx, int dx_pitch, const float* oscale, int flags);
-/* ---- weight gradient: dw (torch layout, fp32) = or += x (*) dy ; ws: tfc_conv_wgrad_ws_bytes() scratch ----------- */
+/* ---- weight gradient: dw (torch layout, fp32) = or += x (*) dy ; ws: tfc_conv_wgrad_ws_bytes() of scratch that must be
+ *      ALL ZERO on entry (zero it once after allocation) and is left all zero on return ------------------------------ */
 size_t tfc_conv_wgrad_ws_bytes(int op, int Cin, int Cout);
 int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, const void* dy, int dy_pitch, int N, int H, int W,
                    int Cin, int Cout, void* ws, float* dw, int accumulate);

@@ -57,6 +57,10 @@ PROTOTYPES = {
     "tfc_abi_version": (_i, []),
     "tfc_conv_packed_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "tfc_conv_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i]),
+    "tfc_pack_plan_bytes": (_sz, [_i]),
+    "tfc_pack_plan_build": (_i, [_i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i),
+                                 _vp, _c.POINTER(_i)]),
+    "tfc_conv_pack_planned": (_i, [_vp, _i, _vp, _i, _i]),
     "tfc_conv_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
     "tfc_patchgan_head_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i]),
     "tfc_conv_dgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i]),

@@ -27,7 +27,8 @@ size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
-hipError_t tfc_launch_wgrad_finish(const float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
+hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
+hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st);
 hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st);
 hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats, void* dx, int use_x, int dx_pitch, hipStream_t st);
 hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, hipStream_t st);
@@ -382,6 +383,48 @@ extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int 
   return 0;
 }
 
+// ---- planned packing: host builds a job table once (geometry and buffers fixed), the caller keeps a device copy ----
+struct TfcPackJob {
+  TfcGather d;
+  const float* w;
+  void* wp;
+  long long sn, sc;
+  int NB32, Nreal, Creal, units;
+  int first_block, pad_;
+};
+extern "C" size_t tfc_pack_plan_bytes(int nlayers) { return (size_t)nlayers * 4 * sizeof(TfcPackJob); }
+// fills plan_host with one job per (layer, pass, phase); returns the number of jobs (<0 on error) and the grid size in *nblocks
+extern "C" int tfc_pack_plan_build(int dt, int nlayers, const int* ops, const int* passes, const float* const* w, void* const* packed,
+                                   const int* Cin, const int* Cout, void* plan_host, int* nblocks) {
+  REQUIRE(nlayers > 0 && ops && passes && w && packed && Cin && Cout && plan_host && nblocks, "bad args");
+  TfcPackJob* jobs = (TfcPackJob*)plan_host;
+  int nj = 0, blk = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    if (int e = check_common(dt, ops[l], 1, 16, 16, Cin[l], Cout[l])) return e;
+    REQUIRE(passes[l] == 0 || passes[l] == 1, "pass must be 0 or 1");
+    for (int ph = 0; ph < num_phases(ops[l], passes[l]); ++ph) {
+      TfcPackJob& j = jobs[nj];
+      WeightMap wm;
+      if (int e = build_desc(ops[l], passes[l], ph, 1, 16, 16, Cin[l], Cout[l], pad8(Cin[l]), pad8(Cout[l]), &j.d, &wm)) return e;
+      j.w = w[l];
+      j.wp = (char*)packed[l] + phase_packed_offset(dt, ops[l], passes[l], Cin[l], Cout[l], ph);
+      j.sn = wm.sn; j.sc = wm.sc; j.Nreal = wm.Nreal; j.Creal = wm.Creal;
+      j.NB32 = tfc_nb32_padded(j.d.Nout);
+      j.units = tfc_total_substeps(j.d, es_of(dt)) * j.NB32 * 64;
+      j.first_block = blk; j.pad_ = 0;
+      blk += (j.units + 255) / 256;
+      ++nj;
+    }
+  }
+  *nblocks = blk;
+  return nj;
+}
+extern "C" int tfc_conv_pack_planned(void* stream, int dt, const void* plan_dev, int njobs, int nblocks) {
+  REQUIRE(plan_dev && njobs > 0 && nblocks > 0, "bad args");
+  CHECK_HIP(tfc_launch_pack_planned(dt, plan_dev, njobs, nblocks, (hipStream_t)stream), "tfc_conv_pack_planned");
+  return 0;
+}
+
 extern "C" int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* w,
                                      void* y, int y_pitch) {
   REQUIRE(dt == TFC_DT_BF16 || dt == TFC_DT_F32, "bad dtype");
@@ -403,8 +446,7 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
   if (int e = check_pitch(dt, dy_pitch, pad8(Cout), "dy")) return e;
   REQUIRE(ws != nullptr && dw != nullptr, "ws / dw null");
   hipStream_t st = (hipStream_t)stream;
-  CHECK_HIP(hipMemsetAsync(ws, 0, tfc_conv_wgrad_ws_bytes(op, Cin, Cout), st), "tfc_conv_wgrad memset");
-  WeightMap wm{};
+  WeightMap wm{};                                                // ws is all-zero on entry (caller zeroes it ONCE) and all-zero again on exit
   {
     ProfScope prof(1, conv_flop(op, N, H, W, Cin, Cout), st);
     for (int ph = 0; ph < num_phases(op, 2); ++ph) {
@@ -413,7 +455,7 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
       CHECK_HIP(tfc_launch_wgrad(dt, d, dy, x, (float*)ws, pad8(Cout), Cout, Cin, st), "tfc_conv_wgrad");
     }
   }
-  CHECK_HIP(tfc_launch_wgrad_finish((const float*)ws, dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
+  CHECK_HIP(tfc_launch_wgrad_finish((float*)ws, dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
   return 0;
 }
 

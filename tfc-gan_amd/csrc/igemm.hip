@@ -603,16 +603,60 @@ tfc_pack_w_kernel(const TfcGather d, const float* __restrict__ w, const float* _
   wp[idx] = pack16<T>(v);
 }
 
+// One launch packs every operand stream of a network: a device-resident plan (built once by the host for fixed geometry and
+// fixed buffers) lists the jobs; a workgroup finds its job from the prefix sums of the unit counts.
+struct TfcPackJob {
+  TfcGather d;
+  const float* w;
+  uint4* wp;
+  long long sn, sc;
+  int NB32, Nreal, Creal, units;                                  // units = 16-byte units of this job
+  int first_block, pad_;                                          // first 256-thread workgroup of this job in the planned grid
+};
+template <typename T>
+__global__ void __launch_bounds__(256)
+tfc_pack_planned_kernel(const TfcPackJob* __restrict__ jobs, int njobs) {
+  constexpr int ES = sizeof(T);
+  constexpr int UE = 16 / ES;
+  int lo = 0, hi = njobs - 1;                                     // last job with first_block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TfcPackJob& j = jobs[lo];
+  const int idx = ((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  if (idx >= j.units) return;
+  int n, mask, c0;
+  tfc_pack_locate(j.d, ES, j.NB32, idx, &n, &mask, &c0);
+  float v[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) {
+    const int c = c0 + e;
+    float a = 0.f;
+    if (n < j.Nreal && c < j.Creal)
+      for (int m = mask; m; m &= m - 1) a += j.w[(long long)n * j.sn + (long long)c * j.sc + (__ffs(m) - 1)];
+    v[e] = a;
+  }
+  j.wp[idx] = pack16<T>(v);
+}
+hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st) {
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_pack_planned_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
+  else hipLaunchKernelGGL((tfc_pack_planned_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
+  return hipGetLastError();
+}
+
 // fp32 accumulator [16 slots][Nn][Cw] -> torch-layout gradient  grad[n*sn + c*sc + slot]
 __global__ void __launch_bounds__(256)
-tfc_wgrad_finish_kernel(const float* __restrict__ acc, float* __restrict__ grad, int Nn, int Cw,
+tfc_wgrad_finish_kernel(float* __restrict__ acc, float* __restrict__ grad, int Nn, int Cw,
                         long long sn, long long sc, int accumulate, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int slot = idx & 15;
   const int rest = idx >> 4;
   const int c = rest % Cw, n = rest / Cw;
-  const float v = acc[((size_t)slot * Nn + n) * Cw + c];
+  float* pa = acc + ((size_t)slot * Nn + n) * Cw + c;
+  const float v = *pa;
+  *pa = 0.f;                                                      // leave the accumulator zeroed for the next wgrad
   float* g = grad + (long long)n * sn + (long long)c * sc + slot;
   *g = accumulate ? (*g + v) : v;
 }
@@ -764,7 +808,7 @@ hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const vo
   return dt == TFC_DT_BF16 ? launch_wgrad_t<bf16_t>(d, dO, in, dwacc, Nn_pad, Nn_real, Cw_real, st)
                            : launch_wgrad_t<float>(d, dO, in, dwacc, Nn_pad, Nn_real, Cw_real, st);
 }
-hipError_t tfc_launch_wgrad_finish(const float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
+hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
                                    int accumulate, hipStream_t st) {
   const int total = Nn * Cw * 16;
   hipLaunchKernelGGL(tfc_wgrad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, acc, grad, Nn, Cw, sn, sc,

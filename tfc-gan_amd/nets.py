@@ -74,24 +74,25 @@ class GeneratorCore:
         """params: dict state_dict-key -> fp32 CUDA tensor in torch layout (may be views into a flat buffer)."""
         self.params = params
         self.packed = {}
+        self._plan = None
 
     def repack(self):
-        dt, P = self.dt, self.params
-        for name, cin, cout, _, _ in G_DOWN:
-            w = P[down_weight_key(name)]
-            ent = self.packed.setdefault(name, {})
-            ent["fwd"] = ops.pack_weight(dt, OP_CONV, 0, w, cin, cout, out=ent.get("fwd"))
-            if name != "down1":
-                ent["dgrad"] = ops.pack_weight(dt, OP_CONV, 1, w, cin, cout, out=ent.get("dgrad"))
-        for name, cin, cout, _, _ in G_UP:
-            w = P[f"{name}.model.0.weight"]
-            ent = self.packed.setdefault(name, {})
-            ent["fwd"] = ops.pack_weight(dt, OP_CONVT, 0, w, cin, cout, out=ent.get("fwd"))
-            ent["dgrad"] = ops.pack_weight(dt, OP_CONVT, 1, w, cin, cout, out=ent.get("dgrad"))
-        w = P["final.2.weight"]
-        ent = self.packed.setdefault("final", {})
-        ent["fwd"] = ops.pack_weight(dt, OP_UPCONV, 0, w, 128, self.channels, out=ent.get("fwd"))
-        ent["dgrad"] = ops.pack_weight(dt, OP_UPCONV, 1, w, 128, self.channels, out=ent.get("dgrad"))
+        """re-pack every operand stream (fwd + dgrad) from the current weights: ONE launch over a device-resident plan"""
+        if getattr(self, "_plan", None) is None:
+            P, jobs, slots = self.params, [], []
+            for name, cin, cout, _, _ in G_DOWN:
+                jobs.append((OP_CONV, 0, P[down_weight_key(name)], cin, cout)); slots.append((name, "fwd"))
+                if name != "down1":
+                    jobs.append((OP_CONV, 1, P[down_weight_key(name)], cin, cout)); slots.append((name, "dgrad"))
+            for name, cin, cout, _, _ in G_UP:
+                for pas, key in ((0, "fwd"), (1, "dgrad")):
+                    jobs.append((OP_CONVT, pas, P[f"{name}.model.0.weight"], cin, cout)); slots.append((name, key))
+            for pas, key in ((0, "fwd"), (1, "dgrad")):
+                jobs.append((OP_UPCONV, pas, P["final.2.weight"], 128, self.channels)); slots.append(("final", key))
+            self._plan = ops.PackPlan(self.dt, jobs)
+            for (name, key), buf in zip(slots, self._plan.streams):
+                self.packed.setdefault(name, {})[key] = buf
+        self._plan.run()
 
     # ---- forward ----
     def forward(self, x, seed=0, train=True, save=True):
@@ -237,16 +238,23 @@ class DiscriminatorCore:
         buffers: dict 'model.{i}.parametrizations.weight.0._u' / '._v' -> fp32 tensors (updated in place)."""
         self.params, self.buffers = params, buffers
         self.head_packed = {}
+        self._plan = None
 
     def repack(self):
-        """operand streams of the UN-normalised weights, once per weight update; 1/sigma is applied in the GEMM epilogue"""
-        w = self.params["model.13.weight"]
-        self.head_packed["fwd"] = ops.pack_weight(self.dt, OP_PADCONV, 0, w, 512, 1, out=self.head_packed.get("fwd"))
-        self.head_packed["dgrad"] = ops.pack_weight(self.dt, OP_PADCONV, 1, w, 512, 1, out=self.head_packed.get("dgrad"))
-        for i, cin, cout in D_BLOCKS:
-            W = self.params[f"model.{i}.parametrizations.weight.original"]
-            self.head_packed[f"f{i}"] = ops.pack_weight(self.dt, OP_CONV, 0, W, cin, cout, out=self.head_packed.get(f"f{i}"))
-            self.head_packed[f"d{i}"] = ops.pack_weight(self.dt, OP_CONV, 1, W, cin, cout, out=self.head_packed.get(f"d{i}"))
+        """operand streams of the UN-normalised weights, once per weight update (one launch); 1/sigma is applied in the GEMM epilogue"""
+        if getattr(self, "_plan", None) is None:
+            jobs, slots = [], []
+            w = self.params["model.13.weight"]
+            jobs.append((OP_PADCONV, 0, w, 512, 1)); slots.append("fwd")
+            jobs.append((OP_PADCONV, 1, w, 512, 1)); slots.append("dgrad")
+            for i, cin, cout in D_BLOCKS:
+                W = self.params[f"model.{i}.parametrizations.weight.original"]
+                jobs.append((OP_CONV, 0, W, cin, cout)); slots.append(f"f{i}")
+                jobs.append((OP_CONV, 1, W, cin, cout)); slots.append(f"d{i}")
+            self._plan = ops.PackPlan(self.dt, jobs)
+            for key, buf in zip(slots, self._plan.streams):
+                self.head_packed[key] = buf
+        self._plan.run()
 
     def forward(self, img_a, img_b, power_iter=True, save=True):
         """img_a, img_b: fp32 NCHW [N,3,S,S]. Returns (logits View [N,S/16,S/16,pitch 8] channel 0, ctx)."""
@@ -297,6 +305,7 @@ class DiscriminatorCore:
         (skip all weight gradients: generator step). Returns fp32 NCHW gradient of img_a (first argument) or None."""
         dt, N = self.dt, ctx.N
         dev = g_logits.t.device
+        ws = getattr(self, "_ws", None) if ws is None else ws     # persistent wgrad scratch (zeroed once, re-zeroed by the kernels)
         gl = View(g_logits.t, 8, 0)
         if grads is not None:
             ws = ops.conv_wgrad(dt, OP_PADCONV, ctx.p4, gl, 512, 1, grads["model.13.weight"], accumulate, ws)
@@ -329,6 +338,7 @@ class DiscriminatorCore:
                 g_in = new_act(N, xin.H, xin.W, xin.pitch, dt, dev)
                 ops.conv_dgrad(dt, OP_CONV, d_raw, N, xin.H, xin.W, cin, cout, self.head_packed[f"d{i}"], g_in, oscale=sigma2[1:])
                 g_cur = g_in
+        self._ws = ws
         if need_input_grad:
             return ops.unpack_nchw(dt, g_cur, self.channels, c0=0)
         return None

@@ -103,6 +103,31 @@ def pack_weight(dt, op, pas, w, Cin, Cout, scale=None, out=None):
     return out
 
 
+class PackPlan:
+    """All operand streams of one network packed by a single launch. jobs: list of (op, pass, weight fp32 tensor, Cin, Cout);
+    the weight tensors and the returned stream buffers must stay where they are (flat parameter buffer, persistent streams)."""
+
+    def __init__(self, dt, jobs):
+        self.dt = dt
+        dev = jobs[0][2].device
+        n = len(jobs)
+        self.streams = [torch.empty(packed_bytes(dt, op, pas, cin, cout), dtype=torch.uint8, device=dev) for op, pas, w, cin, cout in jobs]
+        self.keep = [w for _, _, w, _, _ in jobs]
+        host = (ctypes.c_uint8 * lib().tfc_pack_plan_bytes(n))()
+        nblk = ctypes.c_int(0)
+        ci = lambda xs: (ctypes.c_int * n)(*xs)  # noqa: E731
+        cp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+        nj = lib().tfc_pack_plan_build(dt, n, ci([j[0] for j in jobs]), ci([j[1] for j in jobs]), cp(self.keep), cp(self.streams),
+                                       ci([j[3] for j in jobs]), ci([j[4] for j in jobs]), ctypes.cast(host, ctypes.c_void_p), ctypes.byref(nblk))
+        if nj < 0:
+            check(nj, "tfc_pack_plan_build")
+        self.njobs, self.nblocks = nj, nblk.value
+        self.plan = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        check(lib().tfc_conv_pack_planned(stream_ptr(), self.dt, _p(self.plan), self.njobs, self.nblocks), "tfc_conv_pack_planned")
+
+
 def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stats=None, out_nchw=None, flags=0, oscale=None):
     if bias is not None:
         flags |= EP_BIAS
@@ -127,7 +152,7 @@ def conv_dgrad(dt, op, dy: View, N, H, W, Cin, Cout, packed, dx: View, accumulat
 def conv_wgrad(dt, op, x: View, dy: View, Cin, Cout, dw, accumulate=False, ws=None):
     nbytes = lib().tfc_conv_wgrad_ws_bytes(op, Cin, Cout)
     if ws is None or ws.numel() * ws.element_size() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
+        ws = torch.zeros(max(nbytes, 16 * 1024 * 512 * 4), dtype=torch.uint8, device=x.t.device)   # zero ONCE: the kernels re-zero it
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     check(lib().tfc_conv_wgrad(stream_ptr(), dt, op, x.ptr, x.pitch, dy.ptr, dy.pitch, x.N, x.H, x.W, Cin, Cout, _p(ws), _p(dw),
                                1 if accumulate else 0), "tfc_conv_wgrad")
