@@ -49,6 +49,17 @@ def cpu_baseline(sample_n=8, steps=4):
                       f"torch fp32, {cores} threads, {dt:.1f} s"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of THIS command (FETCH_SIZE and WRITE_SIZE collected in separate
+    runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- profiles/r01_pmc_traffic.json, or None if absent"""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f).get(kernel)
+    return None if d is None else d["hbm_bytes_per_launch_corrected"]
+
+
 def generator_l1(dev):
     """generator L1 vs the oracle on one synthetic image, fp32 parity mode and bf16 mode (the 'gen L1 vs ref' half of the metric)"""
     import torch
@@ -145,7 +156,7 @@ def main():
                        "algorithmic_gflop_per_image": T.TrainStep.STEP_GFLOP},
             "roofline": {"bound": "mfma", "kernel": "tfc_igemm_kernel (halo-staged implicit-GEMM conv: fwd/dgrad/convT/upconv)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": None, "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
+                         "traffic": pmc_traffic("tfc_igemm_kernel"), "traffic_unit": "HBM bytes per launch (PMC)", "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
                          "share_of_step_time": (ig_ms / 1e3) / elapsed,
                          "second_kernel": {"kernel": "tfc_wgrad_kernel", "achieved": (wg_flop / 1e12) / (wg_ms / 1e3) if wg_ms > 0 else 0.0,
                                            "unit": "TFLOP/s", "launches": wg_n, "share_of_step_time": (wg_ms / 1e3) / elapsed}},

@@ -24,6 +24,24 @@ if "act" in which:
     a = rnd(N, 128, 128, 64); b = ops.new_act(N, 128, 128, 64, dt, DEV)
     for _ in range(REP):
         ops.act_bwd(dt, 0, a, None, N, 128, 128, 64, b, slope=1.0, pool=1)
+if "cfg" in which:
+    import time
+    lib = T._lib.load()
+    shapes = [(128, 64, 128), (64, 128, 256), (32, 256, 512)]          # (H, Cin, Cout): down2 / down3 / down4
+    for H, Cin, Cout in shapes:
+        x = rnd(N, H, H, Cin); w = torch.randn(Cout, Cin, 4, 4, device=DEV) * 0.03; y = ops.new_act(N, H - 1, H - 1, Cout, dt, DEV)
+        pk = ops.pack_weight(dt, ops.OP_CONV, 0, w, Cin, Cout)
+        for cfg in (0, 3, 1):
+            lib.tfc_debug_set_igemm_config(cfg)
+            for _ in range(2):
+                ops.conv_fwd(dt, ops.OP_CONV, x, Cin, Cout, pk, y)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10):
+                ops.conv_fwd(dt, ops.OP_CONV, x, Cin, Cout, pk, y)
+            torch.cuda.synchronize(); dtm = (time.perf_counter() - t0) / 10
+            fl = 2.0 * N * (H - 1) ** 2 * Cin * Cout * 16
+            print(f"H={H} {Cin}->{Cout} cfg {cfg}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
+    lib.tfc_debug_set_igemm_config(-1)
 if "igemm" in which:
     # down2 / D2: 64 -> 128 @ 128x128 ; D1: 8 -> 64 @ 256x256
     x = rnd(N, 128, 128, 64); w = torch.randn(128, 64, 4, 4, device=DEV) * 0.03; y = ops.new_act(N, 127, 127, 128, dt, DEV)

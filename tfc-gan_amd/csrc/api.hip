@@ -618,7 +618,7 @@ extern "C" int tfc_adam_step(void* stream, float* p, const float* g, float* m, f
 }
 extern int g_tfc_force_cfg;
 extern "C" int tfc_debug_set_igemm_config(int cfg) {
-  REQUIRE(cfg >= -1 && cfg <= 2, "cfg must be -1 (heuristic), 0 (128x128), 1 (128x64) or 2 (128x32)");
+  REQUIRE(cfg >= -1 && cfg <= 3, "cfg must be -1 (heuristic), 0 (128x128), 1 (128x64) or 2 (128x32)");
   g_tfc_force_cfg = cfg;
   return 0;
 }

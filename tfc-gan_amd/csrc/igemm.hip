@@ -763,6 +763,7 @@ template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
                                  float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   const int nb = tfc_nb32(d.Nout);
+  if (g_tfc_force_cfg == 3 && nb >= 4) return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if (g_tfc_force_cfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if ((g_tfc_force_cfg == 0 || g_tfc_force_cfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if (g_tfc_force_cfg >= 0) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
