@@ -42,6 +42,27 @@ if "cfg" in which:
             fl = 2.0 * N * (H - 1) ** 2 * Cin * Cout * 16
             print(f"H={H} {Cin}->{Cout} cfg {cfg}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
     lib.tfc_debug_set_igemm_config(-1)
+if "stream" in which:
+    import time
+    def timeit(fn, reps=10):
+        for _ in range(2): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
+    raw = rnd(N, 255, 255, 64); dxv = ops.new_act(N, 255, 255, 64, dt, DEV); gfull = rnd(N, 255, 255, 64); gpool = rnd(N, 128, 128, 64)
+    outp = ops.new_act(N, 128, 128, 64, dt, DEV)
+    MB = 1e6
+    t = timeit(lambda: ops.act_bwd(dt, 0, gfull, raw, N, 255, 255, 64, dxv, slope=0.2, pool=0))
+    print(f"act_bwd pool0 (read 2x266MB, write 266MB): {t*1e6:7.1f} us  {(3*266.3*MB)/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: ops.act_bwd(dt, 0, gpool, raw, N, 255, 255, 64, dxv, slope=0.2, pool=2))
+    print(f"act_bwd pool2 (read 266+67MB, write 266MB): {t*1e6:7.1f} us  {((2*266.3+67.1)*MB)/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: ops.act_fwd(dt, raw, outp, stats=None, slope=0.2, pool=2))
+    print(f"act_fwd pool2 (read 266MB, write 67MB): {t*1e6:7.1f} us  {((266.3+67.1)*MB)/t/1e12:5.2f} TB/s")
+    t = timeit(lambda: ops.act_fwd(dt, raw, dxv, stats=None, slope=0.2, pool=0))
+    print(f"act_fwd pool0 (read 266MB, write 266MB): {t*1e6:7.1f} us  {((2*266.3)*MB)/t/1e12:5.2f} TB/s")
+    a32 = torch.randn(N * 255 * 255 * 64 // 2, device=DEV); b32 = torch.empty_like(a32)
+    t = timeit(lambda: b32.copy_(a32))
+    print(f"torch copy 266MB->266MB: {t*1e6:7.1f} us  {(2*a32.numel()*4)/t/1e12:5.2f} TB/s")
 if "igemm" in which:
     # down2 / D2: 64 -> 128 @ 128x128 ; D1: 8 -> 64 @ 256x256
     x = rnd(N, 128, 128, 64); w = torch.randn(128, 64, 4, 4, device=DEV) * 0.03; y = ops.new_act(N, 127, 127, 128, dt, DEV)

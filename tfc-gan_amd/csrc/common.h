@@ -42,12 +42,19 @@ template <> __device__ __forceinline__ void unpack16<float>(const uint4& u, floa
   v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
 }
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* v);
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> one dword of two bf16 (RNE): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* v) {
   uint4 u;
-  u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-  u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-  u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  u.x = pack_bf16x2(v[0], v[1]);
+  u.y = pack_bf16x2(v[2], v[3]);
+  u.z = pack_bf16x2(v[4], v[5]);
+  u.w = pack_bf16x2(v[6], v[7]);
   return u;
 }
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* v) {

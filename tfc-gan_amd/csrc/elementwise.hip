@@ -346,6 +346,179 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
   }
 }
 
+// Stride-2 BlurPool backward, tiled: a workgroup owns a 16 x 32 tile of INPUT pixels and a 64-channel slice. The (10 x 18)-pixel
+// window of the pooled gradient that the tile's interior pixels read is staged ONCE in LDS (with the dropout mask applied once
+// per element, not once per tap); each interior pixel then takes its 2 x 2 taps {3/8,1/8}^2 from LDS. Pixels next to the
+// reflect-padded border (rows/cols 0, 1, n-3, n-2, n-1) use the generic alias enumeration on global memory.
+// MODE as in tfc_act_bwd_kernel.
+template <typename T, int MODE, bool NORM>
+__global__ void __launch_bounds__(256)
+tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats,
+                         float* rstats, T* __restrict__ dx, int dx_pitch, int tiles_x, int cslice) {
+  constexpr int UE = ElemTraits<T>::UE;
+  constexpr int TH = 16, TW = 32, WH = TH / 2 + 3, WW = TW / 2 + 3;   // window 11 x 19 output pixels (covers the reflect aliases too)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int CVS = cslice / UE;                                    // channel vectors of this slice (<= 16)
+  const int PL = 256 / CVS;                                       // pixel lanes
+  const int cvl = threadIdx.x % CVS, pl = threadIdx.x / CVS;
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.z * cslice;
+  const int cvg = c0 / UE + cvl;                                  // global channel-vector index
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const int oyb = ty0 / 2 - 1, oxb = tx0 / 2 - 1;                 // window origin in pooled coordinates
+  const int npix = p.H * p.W, nopix = p.Ho * p.Wo;
+  const T* dn = dout + (size_t)n * nopix * p.o_pitch;
+  const T* xn = x + (size_t)n * npix * p.x_pitch;
+  T* dxn = dx + (size_t)n * npix * dx_pitch;
+  uint4* win = reinterpret_cast<uint4*>(smem_raw);                // [WH][WW][CVS] 16-byte units
+  float* red = reinterpret_cast<float*>(smem_raw + (size_t)WH * WW * CVS * 16);   // [2][256*UE] (MODE 0/1 reductions)
+
+  for (int i = threadIdx.x; i < WH * WW * CVS; i += 256) {
+    const int cv = i % CVS, wp = i / CVS;
+    const int oy = oyb + wp / WW, ox = oxb + wp % WW;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo) {
+      const int opix = oy * p.Wo + ox;
+      v = *reinterpret_cast<const uint4*>(dn + (size_t)opix * p.o_pitch + (c0 / UE + cv) * UE);
+      if (p.drop_thresh24) {
+        float f[UE];
+        unpack16<T>(v, f);
+        const uint32_t base = (uint32_t)(((size_t)n * nopix + opix) * p.C + c0 + cv * UE);
+#pragma unroll
+        for (int e = 0; e < UE; ++e) f[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? f[e] * p.drop_scale : 0.f;
+        v = pack16<T>(f);
+      }
+    }
+    win[i] = v;
+  }
+  float mean[UE], rstd[UE], mg[UE], mgx[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) { mean[e] = 0.f; rstd[e] = 1.f; mg[e] = 0.f; mgx[e] = 0.f; }
+  if (NORM) {
+    const float inv = 1.f / (float)npix;
+#pragma unroll
+    for (int e = 0; e < UE; ++e) {
+      const size_t si = ((size_t)n * p.C + cvg * UE + e) * 2;
+      const float m = stats[si] * inv;
+      mean[e] = m;
+      rstd[e] = rsqrtf(fmaxf(stats[si + 1] * inv - m * m, 0.f) + p.eps);
+      if (MODE == 2) { mg[e] = rstats[si] * inv; mgx[e] = rstats[si + 1] * inv; }
+    }
+  }
+  __syncthreads();
+  float a1[UE], a2[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  auto process = [&](int y, int xq, const uint4& xraw) -> uint4 {
+    float g[UE];
+#pragma unroll
+    for (int e = 0; e < UE; ++e) g[e] = 0.f;
+    if (y >= 2 && y <= p.H - 4 && xq >= 2 && xq <= p.W - 4) {
+      const int wy = ((y + 1) >> 1) - oyb, wx = ((xq + 1) >> 1) - oxb;   // window coords of the (oy0, ox0) tap; the others are -1
+      const float wy0 = (y & 1) ? 0.125f : 0.375f, wx0 = (xq & 1) ? 0.125f : 0.375f;
+      const float wy1 = 0.5f - wy0, wx1 = 0.5f - wx0;
+      float v[UE];
+      unpack16<T>(win[(wy * WW + wx) * CVS + cvl], v);
+#pragma unroll
+      for (int e = 0; e < UE; ++e) g[e] += wy0 * wx0 * v[e];
+      unpack16<T>(win[(wy * WW + wx - 1) * CVS + cvl], v);
+#pragma unroll
+      for (int e = 0; e < UE; ++e) g[e] += wy0 * wx1 * v[e];
+      unpack16<T>(win[((wy - 1) * WW + wx) * CVS + cvl], v);
+#pragma unroll
+      for (int e = 0; e < UE; ++e) g[e] += wy1 * wx0 * v[e];
+      unpack16<T>(win[((wy - 1) * WW + wx - 1) * CVS + cvl], v);
+#pragma unroll
+      for (int e = 0; e < UE; ++e) g[e] += wy1 * wx1 * v[e];
+    } else {
+      for (int ay = 0; ay < 4; ++ay) {
+        if ((ay == 1 && y != 1) || (ay == 2 && y != p.H - 2) || (ay == 3 && y != p.H - 3)) continue;
+        const int py = ay == 0 ? y : (ay == 1 ? -1 : (ay == 2 ? p.H : p.H + 1));
+        for (int ky = 0; ky < 4; ++ky) {
+          const int tyy = py + 1 - ky;
+          if (tyy < 0 || (tyy & 1) || (tyy >> 1) >= p.Ho) continue;
+          for (int ax = 0; ax < 4; ++ax) {
+            if ((ax == 1 && xq != 1) || (ax == 2 && xq != p.W - 2) || (ax == 3 && xq != p.W - 3)) continue;
+            const int px = ax == 0 ? xq : (ax == 1 ? -1 : (ax == 2 ? p.W : p.W + 1));
+            for (int kx = 0; kx < 4; ++kx) {
+              const int txx = px + 1 - kx;
+              if (txx < 0 || (txx & 1) || (txx >> 1) >= p.Wo) continue;
+              // every tap of every pixel of the tile lies inside the staged window: border pixels read LDS as well, so no global
+              // load sits in divergent code (hipcc would otherwise drain vmcnt(0) -- stores included -- at every pixel)
+              const int wyy = min(max((tyy >> 1) - oyb, 0), WH - 1), wxx = min(max((txx >> 1) - oxb, 0), WW - 1);
+              float v[UE];
+              unpack16<T>(win[(wyy * WW + wxx) * CVS + cvl], v);
+              const float w = blur_w(ky) * blur_w(kx);
+#pragma unroll
+              for (int e = 0; e < UE; ++e) g[e] += w * v[e];
+            }
+          }
+        }
+      }
+    }
+    float xv[UE], xh[UE];
+    unpack16<T>(xraw, xv);
+#pragma unroll
+    for (int e = 0; e < UE; ++e) {
+      xh[e] = NORM ? (xv[e] - mean[e]) * rstd[e] : xv[e];
+      g[e] = xh[e] > 0.f ? g[e] : g[e] * p.slope;
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < UE; ++e) { a1[e] += g[e]; a2[e] += g[e] * xh[e]; }
+      return make_uint4(0, 0, 0, 0);
+    }
+    if (MODE == 0 && rstats) {
+#pragma unroll
+      for (int e = 0; e < UE; ++e) a1[e] += g[e];
+    }
+    float r[UE];
+#pragma unroll
+    for (int e = 0; e < UE; ++e) r[e] = (MODE == 2) ? rstd[e] * (g[e] - mg[e] - xh[e] * mgx[e]) : g[e];
+    return pack16<T>(r);
+  };
+  // four pixels per iteration with their x loads issued up front: one dependent load per iteration would leave a single
+  // 16-byte request in flight per lane and starve the memory pipeline
+  for (int tp0 = pl; tp0 < TH * TW; tp0 += 4 * PL) {
+    uint4 xr[4];
+    int yy[4], xx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tp = tp0 + u * PL;
+      yy[u] = ty0 + tp / TW; xx[u] = tx0 + tp % TW;
+      const bool ok = tp < TH * TW && yy[u] < p.H && xx[u] < p.W;
+      if (!ok) yy[u] = -1;
+      xr[u] = ok ? *reinterpret_cast<const uint4*>(xn + (size_t)(yy[u] * p.W + xx[u]) * p.x_pitch + cvg * UE) : make_uint4(0, 0, 0, 0);
+    }
+    // the compute phase touches LDS only; the four results stay in four separate register quads and are stored together at the
+    // end: on this target a store's data VGPRs may not be rewritten before the store completes (hipcc waits vmcnt for it)
+    uint4 res[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) res[u] = yy[u] >= 0 ? process(yy[u], xx[u], xr[u]) : make_uint4(0, 0, 0, 0);
+    if (MODE != 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (yy[u] >= 0) *reinterpret_cast<uint4*>(dxn + (size_t)(yy[u] * p.W + xx[u]) * dx_pitch + cvg * UE) = res[u];
+    }
+  }
+  if (MODE == 1 || (MODE == 0 && rstats)) {
+#pragma unroll
+    for (int e = 0; e < UE; ++e) { red[threadIdx.x * UE + e] = a1[e]; red[256 * UE + threadIdx.x * UE + e] = a2[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cslice; c += 256) {
+      float s1 = 0.f, s2 = 0.f;
+      const int ccv = c / UE, ce = c % UE;
+      for (int q = 0; q < PL; ++q) { s1 += red[(q * CVS + ccv) * UE + ce]; s2 += red[256 * UE + (q * CVS + ccv) * UE + ce]; }
+      if (MODE == 1) {
+        atomicAdd(&rstats[((size_t)n * p.C + c0 + c) * 2 + 0], s1);
+        atomicAdd(&rstats[((size_t)n * p.C + c0 + c) * 2 + 1], s2);
+      } else {
+        atomicAdd(&rstats[(size_t)n * p.C + c0 + c], s1);
+      }
+    }
+  }
+}
+
 // column sums: out[c] += sum over rows of x[row][c]   (bias gradients)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -799,6 +972,22 @@ static void act_bwd_launch(const dim3& grid, const ActParams& p, const void* dou
 template <typename T>
 static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats,
                             void* dx, int use_x, int dx_pitch, hipStream_t st) {
+  if (p.pool == 2 && use_x) {                                     // tiled stride-2 backward (16 x 32 input pixels x 64 channels per workgroup)
+    constexpr int UE = ElemTraits<T>::UE;
+    const int cslice = p.C < 64 ? p.C : 64;
+    if (p.C % cslice == 0 && 256 % (cslice / UE) == 0) {
+      const int tiles_x = (p.W + 31) / 32, tiles_y = (p.H + 15) / 16;
+      const dim3 grid(tiles_x * tiles_y, p.N, p.C / cslice);
+      const size_t lds = (size_t)11 * 19 * (cslice / UE) * 16 + 2 * 256 * UE * sizeof(float);
+      if (mode == 0)                                              // mode 0 is only valid without normalisation, modes 1/2 only with it
+        hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 0, false>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, dx_pitch, tiles_x, cslice);
+      else if (mode == 1)
+        hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 1, true>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, dx_pitch, tiles_x, cslice);
+      else
+        hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 2, true>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, dx_pitch, tiles_x, cslice);
+      return hipGetLastError();
+    }
+  }
   const dim3 grid = act_grid(p.H * p.W, p.C, ElemTraits<T>::UE, p.N);
   if (mode == 0) act_bwd_launch<T, 0>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
   else if (mode == 1) act_bwd_launch<T, 1>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
