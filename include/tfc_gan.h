@@ -124,6 +124,9 @@ int tfc_patch16_triplet(void* stream, const float* fake, const float* real, cons
  * image origin; amp/pha: [N*wins][S][S/2+1] fp32; shift != 0 applies np.fft.fftshift to both axes. */
 int tfc_fft_spectrum(void* stream, const float* img, long long batch_stride, long long chan_stride, int row_stride, int C, int S,
                      int wins_x, int wins_y, int N, float* amp, float* pha, int shift);
+/* evaluation metric of TFC-GAN-FFT/Devcom_MagMSE.py:91-118 (mse_spec): per window MSE(log|fft2(a)|, log|fft2(b)|) over the FULL S x S
+ * spectrum, computed from the half spectra amp_a / amp_b [nwin][S][S/2+1] of tfc_fft_spectrum; out[nwin] */
+int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out);
 /* out[0] (=/+=) scale * sum |a-b| : nn.L1Loss pieces of calculate_ffts, P16:323-375 */
 int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first);
 /* relativistic BCEWithLogits, P16:554 (mode 0) and P16:628-630 (mode 1); a,b: n logits in dt, `stride` elements apart

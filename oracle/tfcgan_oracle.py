@@ -234,6 +234,12 @@ def global_fft_loss(fake_B, real_B):
     return 0.5 * (la + lp), la, lp
 
 
+def mse_spec(real_gray, fake_gray):
+    """TFC-GAN-FFT/Devcom_MagMSE.py:91-118: mean squared error of log|fftshift(fft2(.))| between two float32 gray images."""
+    mag = lambda im: np.log(np.abs(np.fft.fftshift(np.fft.fft2(np.asarray(im, dtype=np.float32)))))  # noqa: E731
+    return float(np.mean((mag(real_gray) - mag(fake_gray)) ** 2))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # adversarial losses, optimiser, the step
 # ---------------------------------------------------------------------------------------------------------------

@@ -350,6 +350,15 @@ def test_fft_spectrum_vs_oracle_and_golden(golden):
     assert z.item() == 0.0
 
 
+def test_mse_spec_eval_metric():
+    rng = np.random.default_rng(5)
+    real = rng.integers(0, 256, size=(3, 256, 256), dtype=np.uint8)
+    fake = np.clip(real.astype(np.int32) + rng.integers(-40, 41, size=real.shape), 0, 255).astype(np.uint8)
+    got = T.mse_spec(real, fake).cpu().numpy()
+    want = np.array([O.mse_spec(real[i], fake[i]) for i in range(3)])
+    np.testing.assert_allclose(got, want, rtol=2e-3)
+
+
 def test_bce_relativistic_golden(golden):
     g = golden("bce_relativistic")
     a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])

@@ -135,3 +135,13 @@ def test_module_state_dict_contract(golden):
     assert T.Discriminator is T.Discriminator1
     with pytest.raises(T.TfcError):                      # CPU modules fail loudly: there is no CPU fallback
         G(torch.zeros(1, 3, 256, 256))
+
+
+def test_dataparallel_prefixed_checkpoint_roundtrip():
+    """reference checkpoints carry nn.DataParallel's 'module.' prefix (P16:692-695); test_TFCGAN_16Patches.py strips it (T16:153-163)"""
+    G = T.GeneratorUNet((3, 256, 256))
+    sd = {"module." + k: v.clone() + 1 for k, v in G.state_dict().items()}
+    clean = {k[7:]: v for k, v in sd.items()}                       # load_clean_state
+    missing = G.load_state_dict(clean)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert torch.equal(G.state_dict()["final.2.bias"], sd["module.final.2.bias"])

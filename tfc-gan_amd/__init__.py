@@ -10,11 +10,11 @@ FFT_Components / fft_components / calculate_ffts, and the fused TrainStep + data
 from . import _lib, engine, losses, models, nets, ops, parallel  # noqa: F401
 from ._lib import TfcError, build  # noqa: F401
 from .engine import TrainStep  # noqa: F401
-from .losses import (ContrastiveLoss, FFT_Components, calculate_ffts, fft_components, global_fft_loss, make_16_patches,  # noqa: F401
+from .losses import (ContrastiveLoss, FFT_Components, calculate_ffts, fft_components, global_fft_loss, make_16_patches, mse_spec,  # noqa: F401
                      patch_fft_loss, patch_first_flat_index, patch_triplet_loss)
 from .models import (BlurPool, Discriminator, Discriminator1, GeneratorUNet, UNetDown, UNetUp, get_compute_dtype,  # noqa: F401
                      set_compute_dtype, weights_init_normal)
 
 __all__ = ["UNetDown", "UNetUp", "GeneratorUNet", "Discriminator1", "Discriminator", "BlurPool", "weights_init_normal",
            "make_16_patches", "ContrastiveLoss", "patch_triplet_loss", "FFT_Components", "fft_components", "calculate_ffts",
-           "patch_fft_loss", "global_fft_loss", "TrainStep", "set_compute_dtype", "get_compute_dtype", "build", "TfcError"]
+           "patch_fft_loss", "global_fft_loss", "mse_spec", "TrainStep", "set_compute_dtype", "get_compute_dtype", "build", "TfcError"]

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "tfc_spectral_norm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "tfc_patch16_triplet": (_i, [_vp, _vp, _vp, _c.POINTER(_i), _i, _i, _vp, _vp, _f]),
     "tfc_fft_spectrum": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
+    "tfc_logmag_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tfc_l1_sum": (_i, [_vp, _vp, _vp, _ll, _f, _vp, _i]),
     "tfc_bce_relativistic": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _f]),
     "tfc_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f]),
@@ -101,8 +102,11 @@ def load():
         if _lib is not None:
             return _lib
         import torch  # noqa: F401  (HIP runtime first)
-        build()
-        lib = ctypes.CDLL(SO_PATH, mode=ctypes.RTLD_GLOBAL)
+        so = os.environ.get("TFC_SO_OVERRIDE")                    # development only: A/B a differently compiled library
+        if not so:
+            build()
+            so = SO_PATH
+        lib = ctypes.CDLL(so, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
             fn.restype = res

@@ -46,6 +46,7 @@ hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int*
 hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img, int nwin, float* amp, float* pha, int shift, hipStream_t st);
 hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st);
 hipError_t tfc_launch_probe(float* out, hipStream_t st);
+hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin, float* out, hipStream_t st);
 hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st);
 struct SnBatch {
   const float* W[4];
@@ -594,6 +595,11 @@ extern "C" int tfc_fft_spectrum(void* stream, const float* img, long long batch_
                                 int wins_x, int wins_y, int N, float* amp, float* pha, int shift) {
   REQUIRE(img && amp && pha && (S == 64 || S == 256) && (C == 1 || C == 3) && wins_x > 0 && wins_y > 0 && N > 0, "bad args");
   CHECK_HIP(tfc_launch_spectrum(img, batch_stride, chan_stride, row_stride, C, S, wins_x, wins_x * wins_y, N * wins_x * wins_y, amp, pha, shift, (hipStream_t)stream), "tfc_fft_spectrum");
+  return 0;
+}
+extern "C" int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out) {
+  REQUIRE(amp_a && amp_b && out && (S == 64 || S == 256) && nwin > 0, "bad args");
+  CHECK_HIP(tfc_launch_logmag_mse(amp_a, amp_b, S, nwin, out, (hipStream_t)stream), "tfc_logmag_mse");
   return 0;
 }
 extern "C" int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first) {

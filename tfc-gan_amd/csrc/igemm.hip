@@ -68,8 +68,14 @@ template <> struct TapPat<4> : TapPatRC<2, 3, false> {};   // upsample-conv phas
 template <> struct TapPat<5> : TapPatRC<3, 2, false> {};
 template <> struct TapPat<6> : TapPatRC<3, 3, false> {};
 
+#ifndef TFC_BD
+#define TFC_BD 4
+#endif
+#ifndef TFC_MINW
+#define TFC_MINW 3
+#endif
 template <typename T, int MT, int NT, int WM, int WN, int PAT>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, TFC_MINW)
 tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __restrict__ wp, T* out,
                  const float* __restrict__ bias, float* stats, float* out_nchw, const float* __restrict__ oscale,
                  int flags, int NB32, int nblkN, int buf_bytes, long long phase_wbytes) {
@@ -79,7 +85,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   constexpr int ES = sizeof(T);
   constexpr int UE = 16 / ES;
   constexpr int P = TFC_LDS_P;
-  constexpr int BD = (PAT == 4 || PAT == 6) ? 2 : 4;              // weight-stream prefetch distance (k-substeps), PAT != 0
+  constexpr int BD = (PAT == 4 || PAT == 6) ? 2 : TFC_BD;         // weight-stream prefetch distance (k-substeps), PAT != 0
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

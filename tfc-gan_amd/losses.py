@@ -155,3 +155,16 @@ def calculate_ffts(*patches):
         ops.l1_sum(af, ar, scale, out[0:1])
         ops.l1_sum(pf, pr, scale, out[1:2])
     return 0.5 * (out[0] + out[1])
+
+
+def mse_spec(real_gray, fake_gray):
+    """Evaluation metric of TFC-GAN-FFT/Devcom_MagMSE.py:91-118: per image pair MSE(log|fftshift(fft2(real))|, log|fftshift(fft2(fake))|).
+    real_gray / fake_gray: uint8 grayscale images [N,256,256] (tensor or array, as cv2.imread(path, 0) yields). Returns [N] fp32."""
+    def prep(g):
+        t = torch.as_tensor(np.asarray(g) if not torch.is_tensor(g) else g)
+        assert t.dtype == torch.uint8 and t.shape[-2:] == (256, 256), "mse_spec expects uint8 [N,256,256] gray images"
+        t = t.reshape(-1, 1, 256, 256).to("cuda", non_blocking=True).float()
+        return (t + 0.5) / 255.0                      # the spectrum kernel truncates x*255 back to the same uint8
+    a, _ = ops.fft_spectrum(prep(real_gray), 256, 1, 1, shift=False)
+    b, _ = ops.fft_spectrum(prep(fake_gray), 256, 1, 1, shift=False)
+    return ops.logmag_mse(a, b)

@@ -296,6 +296,13 @@ def fft_spectrum(img, S, wins_x, wins_y, shift=True):
     return amp, pha
 
 
+def logmag_mse(amp_a, amp_b):
+    nwin, S = amp_a.shape[0], amp_a.shape[1]
+    out = torch.empty(nwin, dtype=torch.float32, device=amp_a.device)
+    check(lib().tfc_logmag_mse(stream_ptr(), _p(amp_a), _p(amp_b), S, nwin, _p(out)), "tfc_logmag_mse")
+    return out
+
+
 def l1_sum(a, b, scale, out, zero_first=False):
     check(lib().tfc_l1_sum(stream_ptr(), _p(a), _p(b), a.numel(), scale, _p(out), 1 if zero_first else 0), "tfc_l1_sum")
 
