@@ -127,6 +127,16 @@ int tfc_fft_spectrum(void* stream, const float* img, long long batch_stride, lon
 /* evaluation metric of TFC-GAN-FFT/Devcom_MagMSE.py:91-118 (mse_spec): per window MSE(log|fft2(a)|, log|fft2(b)|) over the FULL S x S
  * spectrum, computed from the half spectra amp_a / amp_b [nwin][S][S/2+1] of tfc_fft_spectrum; out[nwin] */
 int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out);
+/* temperature head, P16:255-268 (vectorize_temps) over TFC-GAN-FFT/datasets_temp.py:14-35 (TempVector_PyTorch): the red channel of
+ * ToPILImage(img[n]) = (uint8) trunc(x*255) (wraps mod 256) looked up in lut256 (float32(np.linspace(24,38,256)), device).
+ * img: fp32 NCHW, channel 0 is read ([n*batch_stride + y*row_stride + x]); out: [N][H][W] fp32 temperatures in Celsius. */
+int tfc_vectorize_temps(void* stream, const float* img, long long batch_stride, int row_stride, int N, int H, int W,
+                        const float* lut256, float* out);
+/* nn.TripletMarginLoss(margin, p=2, eps=1e-6) on row-major [rows][W] fp32 operands (distance over the last dim, mean over rows):
+ * criterion_temp of P16:80, :595.  loss[0] = mean_rows max(margin + ||a-p+eps|| - ||a-n+eps||, 0).  Forward only (the
+ * reference's temperature term carries no gradient: tensor -> PIL -> numpy, P16:263-265). */
+int tfc_row_triplet(void* stream, const float* anchor, const float* positive, const float* negative, long long rows, int W,
+                    float margin, float* loss);
 /* out[0] (=/+=) scale * sum |a-b| : nn.L1Loss pieces of calculate_ffts, P16:323-375 */
 int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first);
 /* relativistic BCEWithLogits, P16:554 (mode 0) and P16:628-630 (mode 1); a,b: n logits in dt, `stride` elements apart

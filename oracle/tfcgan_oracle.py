@@ -241,6 +241,53 @@ def mse_spec(real_gray, fake_gray):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# temperature head (forward-only; P16:255-268, :587-595 over datasets_temp.py:14-35)
+# ---------------------------------------------------------------------------------------------------------------
+TEMP_T = np.linspace(24, 38, num=256)       # P16:256 / datasets_temp.py:43: Celsius per uint8 code
+
+
+def vectorize_temps(fake_B):
+    """P16:260-268: per sample ToPILImage(...).convert("RGB") -> red channel (datasets_temp.py:33) -> dict lookup
+    (np.searchsorted over the sorted keys 0..255 = plain indexing) -> torch.Tensor (float32); [N,1,H,W]."""
+    out = [torch.tensor(TEMP_T[to_pil_uint8(fake_B[t])[:, :, 0]], dtype=torch.float32) for t in range(fake_B.shape[0])]
+    return torch.stack(out)[:, None]
+
+
+def temp_triplet_loss(fake_B, TB, B_tf, lambda_t=10.0):
+    """P16:587-595: nn.TripletMarginLoss(margin=1, p=2)(TFB_, TB[N,1,H,W], TBTF) * lambda_t."""
+    tb = TB.reshape(TB.size(0), 1, TB.size(-2), TB.size(-1)).to(torch.float32)
+    return F.triplet_margin_loss(vectorize_temps(fake_B), tb, vectorize_temps(B_tf), margin=1.0, p=2) * lambda_t
+
+
+def temp_head_case(seed=71, n=2):
+    """Seeded inputs for the temperature-head fixture: fake_B (with negatives -> uint8 wrap), dataset temperatures TB near the fake
+    ones, and a perturbed negative source, so that the hinge is active on part of the rows."""
+    fake, _ = synthetic_pairs(n, seed=seed)
+    fake = torch.tanh(fake * 1.5)
+    rng = np.random.default_rng(seed + 1)
+    neg_src = torch.tanh(fake * 1.5 + torch.from_numpy(rng.standard_normal(tuple(fake.shape)).astype(np.float32)) * 0.35)
+    TB = vectorize_temps(fake)[:, 0] + torch.from_numpy(rng.standard_normal((n, 256, 256)).astype(np.float32)) * 4.0
+    return fake, TB, neg_src
+
+
+def color_jitter_thermal(real_B, params):
+    """torchvision ColorJitter restricted to R=G=B inputs, explicit parameters (parity unpinned: torchvision absent). Mirrors
+    the product helper so the negatives of the temperature term can be regenerated on both sides."""
+    x = real_B.float()
+    for op in params["order"]:
+        if op == 0:
+            x = (x * params["brightness"]).clamp(0.0, 1.0)
+        elif op == 1:
+            f = params["contrast"]
+            mean = (0.9999 * x[:, :1]).mean(dim=(1, 2, 3), keepdim=True)
+            x = (f * x + (1.0 - f) * mean).clamp(0.0, 1.0)
+        elif op == 2:
+            f = params["saturation"]
+            x = (f * x + (1.0 - f) * 0.9999 * x).clamp(0.0, 1.0)
+    return x
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # adversarial losses, optimiser, the step
 # ---------------------------------------------------------------------------------------------------------------
 def loss_gan_generator(pred_fake, real_pred, valid=0.9):

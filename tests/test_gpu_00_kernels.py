@@ -359,6 +359,25 @@ def test_mse_spec_eval_metric():
     np.testing.assert_allclose(got, want, rtol=2e-3)
 
 
+def test_temperature_head(golden):
+    g = golden("temp_head")
+    tf_, TB, b_tf = O.temp_head_case(71)
+    tfb = T.vectorize_temps(tf_.to(DEV)).cpu()
+    assert torch.equal(tfb, O.vectorize_temps(tf_))                             # LUT of uint8 codes: bit-exact
+    assert torch.equal(tfb[:, :, ::8, ::8], torch.from_numpy(g["tfb_sub"]))
+    loss = T.temperature_triplet_loss(tf_.to(DEV), TB.to(DEV), b_tf.to(DEV)).item()
+    assert abs(loss - float(g["loss_temp_g"])) < 1e-5 * abs(float(g["loss_temp_g"]))
+    assert abs(loss - float(O.temp_triplet_loss(tf_, TB, b_tf))) < 1e-5 * abs(loss)
+    # row triplet on ragged widths against torch
+    for W, rows in ((5, 7), (64, 33), (300, 9)):
+        a, p, n = rnd((rows, W), 1), rnd((rows, W), 2), rnd((rows, W), 3)
+        got = ops.row_triplet(a.to(DEV), p.to(DEV), n.to(DEV)).item()
+        assert abs(got - F.triplet_margin_loss(a, p, n, margin=1.0, p=2).item()) < 1e-5
+    # the jitter helper mirrors the oracle's (parity unpinned against torchvision, which is absent)
+    prm = T.color_jitter_params(np.random.default_rng(3))
+    assert torch.allclose(T.color_jitter_thermal(b_tf.to(DEV), prm).cpu(), O.color_jitter_thermal(b_tf, prm), atol=1e-6)
+
+
 def test_bce_relativistic_golden(golden):
     g = golden("bce_relativistic")
     a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])

@@ -166,10 +166,18 @@ def test_full_size_properties_batch32():
     G.apply(T.weights_init_normal)
     D.apply(T.weights_init_normal)
     ts = T.TrainStep(G, D)
-    out = ts.step(A, B)
+    TB = 24 + 14 * torch.randint(0, 256, (N, 256, 256), device=DEV).float() / 255
+    B_tf = T.color_jitter_thermal(B, T.color_jitter_params(np.random.default_rng(1)))
+    out = ts.step(A, B, T_B=TB, B_tf=B_tf)
     torch.cuda.synchronize()
     fake = out["fake_B"]
     assert fake.shape == (N, 3, 256, 256) and torch.isfinite(fake).all() and fake.abs().max().item() <= 1.0
+    # temperature term (gradient-free, P16:587-595 / :607): the engine's value == the oracle's on the same fake_B
+    want_t = float(O.temp_triplet_loss(fake[:4].cpu(), TB[:4].cpu(), B_tf[:4].cpu()))
+    got_t = T.temperature_triplet_loss(fake[:4], TB[:4], B_tf[:4]).item()
+    assert abs(got_t - want_t) <= 1e-5 * abs(want_t)
+    lg = 0.5 * out["loss_GAN_g"] + out["loss_triplet_patch"] + 0.01 * out["loss_FFT"] + 0.5 * out["loss_temp_g"]
+    assert abs(float(lg) - float(out["loss_G"])) <= 1e-4 * abs(float(lg))
     for k, v in out.items():
         if k != "fake_B":
             assert np.isfinite(float(v)), k

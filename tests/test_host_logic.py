@@ -145,3 +145,28 @@ def test_dataparallel_prefixed_checkpoint_roundtrip():
     missing = G.load_state_dict(clean)
     assert not missing.missing_keys and not missing.unexpected_keys
     assert torch.equal(G.state_dict()["final.2.bias"], sd["module.final.2.bias"])
+
+
+def test_checkpoint_helpers_and_stitch(tmp_path):
+    """save_checkpoint writes the 'module.'-prefixed file of P16:692-695; load_clean_state (T16:153-163) reads it back; the
+    stitch grid of T16:217-263 puts fake patch k over real patch k in channel group k."""
+    G = T.GeneratorUNet((3, 256, 256))
+    with torch.no_grad():
+        for p_ in G.parameters():
+            p_.add_(0.5)
+    path = str(tmp_path / "generator_0.pth")
+    T.save_checkpoint(G, path)
+    raw = torch.load(path, weights_only=True)
+    assert all(k.startswith("module.") for k in raw) and len(raw) == len(G.state_dict())
+    G2 = T.load_clean_state(T.GeneratorUNet((3, 256, 256)), path)
+    for (k, a), (_, b) in zip(G.state_dict().items(), G2.state_dict().items()):
+        assert torch.equal(a, b), k
+    f = torch.arange(2 * 3 * 256 * 256, dtype=torch.float32).reshape(2, 3, 256, 256)
+    r = -f
+    grid = T.stitch_16_patches(f, r)
+    assert grid.shape == (2, 48, 128, 64)
+    for k in (0, 5, 15):
+        y0, x0 = 64 * (k // 4), 64 * (k % 4)
+        assert torch.equal(grid[:, 3 * k:3 * k + 3, :64], f[:, :, y0:y0 + 64, x0:x0 + 64])
+        assert torch.equal(grid[:, 3 * k:3 * k + 3, 64:], r[:, :, y0:y0 + 64, x0:x0 + 64])
+    assert T.global_grid(f, r, f).shape == (2, 3, 768, 256)

@@ -104,6 +104,17 @@ def test_fft_head(golden):
     assert q[0, :, 0].tolist() == [1, 129, 255, 254, 127]
 
 
+def test_temperature_head(golden):
+    g = golden("temp_head")
+    assert np.array_equal(g["lut"], O.TEMP_T)                                   # P16:256-257 dict values, float64 bit-exact
+    tf_, TB, b_tf = O.temp_head_case(71)
+    tfb = O.vectorize_temps(tf_)
+    assert tfb.shape == (2, 1, 256, 256)
+    assert torch.equal(tfb[:, :, ::8, ::8], t(g["tfb_sub"]))
+    assert abs(float(tfb.mean()) - float(g["tfb_mean"])) < 1e-5
+    assert abs(float(O.temp_triplet_loss(tf_, TB, b_tf)) - float(g["loss_temp_g"])) < 1e-5 * abs(float(g["loss_temp_g"]))
+
+
 def test_spectral_norm(golden):
     g = golden("spectral_norm")
     D = O.init_weights_portable(O.Discriminator1((3, 256, 256)), seed=5)

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "tfc_patch16_triplet": (_i, [_vp, _vp, _vp, _c.POINTER(_i), _i, _i, _vp, _vp, _f]),
     "tfc_fft_spectrum": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
     "tfc_logmag_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "tfc_vectorize_temps": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _vp, _vp]),
+    "tfc_row_triplet": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
     "tfc_l1_sum": (_i, [_vp, _vp, _vp, _ll, _f, _vp, _i]),
     "tfc_bce_relativistic": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _f]),
     "tfc_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f]),

@@ -47,6 +47,9 @@ hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int
 hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st);
 hipError_t tfc_launch_probe(float* out, hipStream_t st);
 hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin, float* out, hipStream_t st);
+hipError_t tfc_launch_vectorize_temps(const float* x, long long bs, int rs, int N, int H, int W, const float* lut, float* out, hipStream_t st);
+hipError_t tfc_launch_row_triplet(const float* a, const float* p, const float* ng, long long rows, int W, float margin, float eps,
+                                  float* loss, hipStream_t st);
 hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st);
 struct SnBatch {
   const float* W[4];
@@ -600,6 +603,18 @@ extern "C" int tfc_fft_spectrum(void* stream, const float* img, long long batch_
 extern "C" int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out) {
   REQUIRE(amp_a && amp_b && out && (S == 64 || S == 256) && nwin > 0, "bad args");
   CHECK_HIP(tfc_launch_logmag_mse(amp_a, amp_b, S, nwin, out, (hipStream_t)stream), "tfc_logmag_mse");
+  return 0;
+}
+extern "C" int tfc_vectorize_temps(void* stream, const float* img, long long batch_stride, int row_stride, int N, int H, int W,
+                                  const float* lut256, float* out) {
+  REQUIRE(img && lut256 && out && N > 0 && H > 0 && W > 0 && row_stride >= W && batch_stride >= (long long)H * row_stride, "bad args");
+  CHECK_HIP(tfc_launch_vectorize_temps(img, batch_stride, row_stride, N, H, W, lut256, out, (hipStream_t)stream), "tfc_vectorize_temps");
+  return 0;
+}
+extern "C" int tfc_row_triplet(void* stream, const float* anchor, const float* positive, const float* negative, long long rows, int W,
+                              float margin, float* loss) {
+  REQUIRE(anchor && positive && negative && loss && rows > 0 && W > 0, "bad args");
+  CHECK_HIP(tfc_launch_row_triplet(anchor, positive, negative, rows, W, margin, 1e-6f, loss, (hipStream_t)stream), "tfc_row_triplet");
   return 0;
 }
 extern "C" int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first) {

@@ -168,6 +168,71 @@ hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Temperature head (reference :255-268 vectorize_temps + datasets_temp.py:14-35 TempVector_PyTorch, loss :587-595).
+//   vectorize : red channel of ToPILImage(x) = (uint8) trunc(x*255) (wraps mod 256) -> lut[u8]  (lut = float32(np.linspace(24,38,256)))
+//   row triplet: F.triplet_margin_loss on [N,1,H,W] tensors: d(x,y) = ||x - y + eps||_2 over the last dim (one image row),
+//                loss = mean_rows max(margin + d(a,p) - d(a,n), 0).  One wave per row.  No gradient (the reference detaches via PIL).
+// ---------------------------------------------------------------------------------------------------
+static __device__ TfcRedSlot g_rowtrip_slot;
+
+__global__ void __launch_bounds__(256)
+tfc_vectorize_temps_kernel(const float* __restrict__ x, long long bs, int rs, int H, int W, long long total,
+                           const float* __restrict__ lut, float* __restrict__ out) {
+  __shared__ float sl[256];
+  sl[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int xw = (int)(i % W);
+    const long long r = i / W;
+    const int y = (int)(r % H);
+    const long long n = r / H;
+    const float v = x[(size_t)n * bs + (size_t)y * rs + xw] * 255.f;
+    out[i] = sl[((int)v) & 255];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+tfc_row_triplet_kernel(const float* __restrict__ a, const float* __restrict__ p, const float* __restrict__ ng, long long rows, int W,
+                       float margin, float eps, float* loss) {
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  float lsum = 0.f;
+  for (long long row = (long long)blockIdx.x * 4 + w; row < rows; row += (long long)gridDim.x * 4) {
+    const size_t o = (size_t)row * W;
+    float sp = 0.f, sn = 0.f;
+    for (int xw = lane; xw < W; xw += 64) {
+      const float av = a[o + xw];
+      const float dp = av - p[o + xw] + eps, dn = av - ng[o + xw] + eps;
+      sp += dp * dp; sn += dn * dn;
+    }
+    sp = wave_sum(sp); sn = wave_sum(sn);
+    const float hinge = margin + sqrtf(sp) - sqrtf(sn);
+    if (hinge > 0.f) lsum += hinge;
+  }
+  if (lane == 0) red[w] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    tfc_block_commit(&g_rowtrip_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (double)rows, loss);
+}
+hipError_t tfc_launch_vectorize_temps(const float* x, long long bs, int rs, int N, int H, int W, const float* lut, float* out, hipStream_t st) {
+  const long long total = (long long)N * H * W;
+  long long nb = (total + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(tfc_vectorize_temps_kernel, dim3((int)nb), dim3(256), 0, st, x, bs, rs, H, W, total, lut, out);
+  return hipGetLastError();
+}
+hipError_t tfc_launch_row_triplet(const float* a, const float* p, const float* ng, long long rows, int W, float margin, float eps,
+                                  float* loss, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (e != hipSuccess) return e;
+  long long nb = (rows + 3) / 4;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(tfc_row_triplet_kernel, dim3((int)nb), dim3(256), 0, st, a, p, ng, rows, W, margin, eps, loss);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int* neg_idx, int N, int C, float margin, float eps,
                                 float* loss, float* dfake, float gscale, hipStream_t st) {
   NegIdx ni;

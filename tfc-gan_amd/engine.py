@@ -6,9 +6,9 @@
     D step : pr = D(B, A); pf = D(fake.detach(), A); loss_D = 0.5 * [BCE(pr - pf, 0.9) + BCE(pf - pr, 0)]          (:623-630)
              backward; Adam(D)
 
-Scope notes: LPIPS (:598) and the temperature head (:587-595) are not part of this path (LPIPS needs
-VGG weights that cannot be fetched offline; the temperature term has zero gradient); `extra_loss_G` lets a caller add
-them.  The FFT term carries no gradient in the reference (tensor -> PIL -> numpy, :300-302) and none here.  bf16 needs no
+Scope notes: LPIPS (:598) needs VGG weights that cannot be fetched offline; `extra_loss_G` lets a caller
+plug it in.  The temperature head (:587-595, zero gradient) is computed when the caller passes `T_B` (and the augmented
+negatives `B_tf`): it adds 0.5 * loss_temp_g to the logged loss_G exactly as :607 does.  The FFT term carries no gradient in the reference (tensor -> PIL -> numpy, :300-302) and none here.  bf16 needs no
 GradScaler (:518); the reference's wasted D weight-gradients during the G step (:619 zeroes them) are simply not computed.
 """
 import math
@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import nets, ops, parallel
-from .losses import global_fft_loss, patch_fft_loss
+from .losses import global_fft_loss, patch_fft_loss, temperature_triplet_loss
 from .ops import DT_BF16
 
 
@@ -61,8 +61,9 @@ class TrainStep:
     def _gl(self, like):
         return ops.new_act(like.N, like.H, like.W, 8, self.dt, self.dev, zero=True)
 
-    def step(self, real_A, real_B, neg_idx=None, extra_loss_G=None):
-        """real_A, real_B: fp32 NCHW [N,3,256,256] in [-1,1] on the GPU (this rank's shard). Returns a dict of device scalars."""
+    def step(self, real_A, real_B, neg_idx=None, extra_loss_G=None, T_B=None, B_tf=None):
+        """real_A, real_B: fp32 NCHW [N,3,256,256] in [-1,1] on the GPU (this rank's shard). Returns a dict of device scalars.
+        T_B [N,256,256] + B_tf [N,3,256,256] (augmented real_B) switch the gradient-free temperature term on."""
         dt = self.dt
         self.step_no += 1
         t = self.step_no
@@ -101,9 +102,15 @@ class TrainStep:
         ops.adam_step(self.dflat.data, self.dflat.grad, self.dm, self.dv, self.lr, self.b1, self.b2, self.eps, t, dscale)
         self.D.repack()
         loss_g = self.lambda_gan * loss_gan + loss_trip + self.lambda_fft * loss_fft
+        loss_temp = None
+        if T_B is not None:
+            loss_temp = temperature_triplet_loss(fake, T_B, B_tf if B_tf is not None else real_B)
+            loss_g = loss_g + 0.5 * loss_temp
         self.last = {"loss_G": loss_g.reshape(()), "loss_GAN_g": loss_gan.reshape(()), "loss_triplet_patch": loss_trip.reshape(()),
                      "loss_FFT": loss_fft.reshape(()), "loss_Amp": loss_amp, "loss_Pha": loss_pha, "loss_D": loss_d.reshape(()),
                      "fake_B": fake}
+        if loss_temp is not None:
+            self.last["loss_temp_g"] = loss_temp
         return self.last
 
     # algorithmic work of one step per image: conv / convT MACs x 2

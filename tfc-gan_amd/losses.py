@@ -157,6 +157,62 @@ def calculate_ffts(*patches):
     return 0.5 * (out[0] + out[1])
 
 
+# ---- temperature head (rank 1 of SURVEY.md section 8f; reference :255-268, :587-595) -------------------------------------------
+T = np.linspace(24, 38, num=256)                      # reference :256 -- Celsius per uint8 code
+_LUT = {}
+
+
+def _temp_lut(dev):
+    if dev not in _LUT:
+        _LUT[dev] = torch.from_numpy(T.astype(np.float32)).to(dev)
+    return _LUT[dev]
+
+
+def vectorize_temps(fake_B):
+    """reference :260-268: per sample ToPILImage -> red channel uint8 -> temperature LUT; returns [N,1,H,W] fp32 (no gradient)."""
+    t = ops.vectorize_temps(fake_B.detach(), _temp_lut(fake_B.device))
+    return t.reshape(t.shape[0], 1, t.shape[1], t.shape[2])
+
+
+def temperature_triplet_loss(fake_B, TB, B_tf, lambda_t=10.0):
+    """loss_temp_g of reference :587-595: criterion_temp(vectorize_temps(fake_B), TB, vectorize_temps(B_tf)) * lambda_t.
+    TB: [N,H,W] (or [N,1,H,W]) ground-truth temperatures from the dataset (datasets_temp.py:66-67); B_tf: the augmented real_B
+    that serves as negative (the reference draws it with torchvision ColorJitter, :591-592 -- see color_jitter_thermal)."""
+    tfb = ops.vectorize_temps(fake_B.detach(), _temp_lut(fake_B.device))
+    tneg = ops.vectorize_temps(B_tf.detach(), _temp_lut(fake_B.device))
+    tb = TB.reshape(tfb.shape).to(tfb.device, torch.float32)
+    return ops.row_triplet(tfb, tb, tneg, 1.0).reshape(()) * lambda_t
+
+
+def color_jitter_params(rng, brightness=0.5, contrast=0.75, saturation=1.5, hue=0.5):
+    """The random draw of transforms.ColorJitter(brightness=0.5, contrast=0.75, saturation=1.5, hue=0.5) (reference :591) as
+    explicit values: op order (permutation of 0..3 = brightness, contrast, saturation, hue) and the four factors."""
+    return {"order": [int(i) for i in rng.permutation(4)],
+            "brightness": float(rng.uniform(max(0.0, 1 - brightness), 1 + brightness)),
+            "contrast": float(rng.uniform(max(0.0, 1 - contrast), 1 + contrast)),
+            "saturation": float(rng.uniform(max(0.0, 1 - saturation), 1 + saturation)),
+            "hue": float(rng.uniform(-hue, hue))}
+
+
+def color_jitter_thermal(real_B, params):
+    """ColorJitter restricted to thermal images (R = G = B, datasets_temp.py:33): brightness and contrast are blends clamped to
+    [0,1]; saturation blends with the luma 0.2989R+0.587G+0.114B (= 0.9999 v on grey); hue leaves grey pixels unchanged.
+    torchvision is not installed here, so this restates its published tensor semantics -- PARITY UNPINNED; it only prepares
+    the negatives of the (gradient-free) temperature term and is plain elementwise torch, not a kernel."""
+    x = real_B.float()
+    for op in params["order"]:
+        if op == 0:
+            x = (x * params["brightness"]).clamp(0.0, 1.0)
+        elif op == 1:
+            f = params["contrast"]
+            mean = (0.9999 * x[:, :1]).mean(dim=(1, 2, 3), keepdim=True)
+            x = (f * x + (1.0 - f) * mean).clamp(0.0, 1.0)
+        elif op == 2:
+            f = params["saturation"]
+            x = (f * x + (1.0 - f) * 0.9999 * x).clamp(0.0, 1.0)
+    return x
+
+
 def mse_spec(real_gray, fake_gray):
     """Evaluation metric of TFC-GAN-FFT/Devcom_MagMSE.py:91-118: per image pair MSE(log|fftshift(fft2(real))|, log|fftshift(fft2(fake))|).
     real_gray / fake_gray: uint8 grayscale images [N,256,256] (tensor or array, as cv2.imread(path, 0) yields). Returns [N] fp32."""

@@ -303,6 +303,30 @@ def logmag_mse(amp_a, amp_b):
     return out
 
 
+def vectorize_temps(img, lut):
+    """img: fp32 [N,C,H,W] (unit stride on W); lut: fp32 [256] on the device. Returns [N,H,W] fp32 (channel 0 -> uint8 -> lut)."""
+    require_gpu(img)
+    if img.dtype != torch.float32:
+        img = img.float()
+    if img.stride(3) != 1:
+        img = img.contiguous()
+    N, _, H, W = img.shape
+    out = torch.empty((N, H, W), dtype=torch.float32, device=img.device)
+    check(lib().tfc_vectorize_temps(stream_ptr(), _p(img), img.stride(0), img.stride(2), N, H, W, _p(lut), _p(out)), "tfc_vectorize_temps")
+    return out
+
+
+def row_triplet(anchor, positive, negative, margin=1.0):
+    """nn.TripletMarginLoss(margin, p=2) over the last dim of three equal-shape contiguous fp32 tensors -> scalar [1]."""
+    require_gpu(anchor)
+    assert anchor.shape == positive.shape == negative.shape
+    a, p_, n = (t.float().contiguous() for t in (anchor, positive, negative))
+    W = a.shape[-1]
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(lib().tfc_row_triplet(stream_ptr(), _p(a), _p(p_), _p(n), a.numel() // W, W, float(margin), _p(out)), "tfc_row_triplet")
+    return out
+
+
 def l1_sum(a, b, scale, out, zero_first=False):
     check(lib().tfc_l1_sum(stream_ptr(), _p(a), _p(b), a.numel(), scale, _p(out), 1 if zero_first else 0), "tfc_l1_sum")
 
