@@ -178,6 +178,8 @@ def oracle_act(x, norm, slope, pool, mask=None, drop_p=0.0):
 ACT_CASES = [  # C, H, W, norm, slope, pool, drop
     (64, 15, 15, True, 0.2, 2, 0.0), (128, 7, 7, True, 0.2, 2, 0.5), (64, 31, 30, False, 0.2, 2, 0.0), (512, 8, 8, True, 0.0, 0, 0.5),
     (64, 14, 14, False, 1.0, 1, 0.0), (256, 3, 3, True, 0.2, 2, 0.0), (8, 9, 9, False, 0.2, 2, 0.0),
+    (128, 37, 50, False, 1.0, 1, 0.0), (64, 4, 5, False, 1.0, 1, 0.0), (64, 8, 33, False, 1.0, 1, 0.0), (64, 19, 67, False, 0.2, 2, 0.0),
+    (8, 6, 7, False, 1.0, 1, 0.0),
 ]
 
 

@@ -348,8 +348,8 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
 
 // Stride-2 BlurPool backward, tiled: a workgroup owns a 16 x 32 tile of INPUT pixels and a 64-channel slice. The (10 x 18)-pixel
 // window of the pooled gradient that the tile's interior pixels read is staged ONCE in LDS (with the dropout mask applied once
-// per element, not once per tap); each interior pixel then takes its 2 x 2 taps {3/8,1/8}^2 from LDS. Pixels next to the
-// reflect-padded border (rows/cols 0, 1, n-3, n-2, n-1) use the generic alias enumeration on global memory.
+// per element, not once per tap); each pixel then takes its 2 x 2 taps (3 x 3 next to the bottom / right reflect border) from
+// LDS with weights tabulated per tile row / column, so interior and border pixels run the same short code.
 // MODE as in tfc_act_bwd_kernel.
 template <typename T, int MODE, bool NORM>
 __global__ void __launch_bounds__(256)
@@ -371,8 +371,33 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
   const T* xn = x + (size_t)n * npix * p.x_pitch;
   T* dxn = dx + (size_t)n * npix * dx_pitch;
   uint4* win = reinterpret_cast<uint4*>(smem_raw);                // [WH][WW][CVS] 16-byte units
-  float* red = reinterpret_cast<float*>(smem_raw + (size_t)WH * WW * CVS * 16);   // [2][256*UE] (MODE 0/1 reductions)
+  float4* wrow = reinterpret_cast<float4*>(smem_raw + (size_t)WH * WW * CVS * 16);   // [TH] tap weights of pooled rows oy0-1, oy0, oy0+1
+  float4* wcol = wrow + TH;                                       // [TW] same for columns
+  float* red = reinterpret_cast<float*>(smem_raw);                // [2][256*UE] MODE 0/1 reductions: reuses the window after the main loop
 
+  // Per input row y the transposed blur touches pooled rows oy0-1, oy0, oy0+1 with oy0 = (y+1)>>1 (the third one only through the
+  // reflect aliases next to the bottom / right border). The weights -- reflect aliases merged -- are tabulated once per tile, so
+  // the per-pixel code is the same short sequence for interior and border pixels.
+  if (threadIdx.x < TH + TW) {
+    const bool isrow = threadIdx.x < TH;
+    const int q = isrow ? ty0 + threadIdx.x : tx0 + (threadIdx.x - TH);
+    const int L = isrow ? p.H : p.W, Lo = isrow ? p.Ho : p.Wo;
+    float w3[3] = {0.f, 0.f, 0.f};
+    if (q < L) {
+      const int o0 = (q + 1) >> 1;
+      for (int a = 0; a < 4; ++a) {
+        if ((a == 1 && q != 1) || (a == 2 && q != L - 2) || (a == 3 && q != L - 3)) continue;
+        const int pq = a == 0 ? q : (a == 1 ? -1 : (a == 2 ? L : L + 1));
+        for (int k = 0; k < 4; ++k) {
+          const int t = pq + 1 - k;
+          if (t < 0 || (t & 1) || (t >> 1) >= Lo) continue;
+          const int d = (t >> 1) - o0 + 1;
+          if (d == 0) w3[0] += blur_w(k); else if (d == 1) w3[1] += blur_w(k); else if (d == 2) w3[2] += blur_w(k);
+        }
+      }
+    }
+    (isrow ? wrow[threadIdx.x] : wcol[threadIdx.x - TH]) = make_float4(w3[0], w3[1], w3[2], 0.f);
+  }
   for (int i = threadIdx.x; i < WH * WW * CVS; i += 256) {
     const int cv = i % CVS, wp = i / CVS;
     const int oy = oyb + wp / WW, ox = oxb + wp % WW;
@@ -413,48 +438,18 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
     float g[UE];
 #pragma unroll
     for (int e = 0; e < UE; ++e) g[e] = 0.f;
-    if (y >= 2 && y <= p.H - 4 && xq >= 2 && xq <= p.W - 4) {
-      const int wy = ((y + 1) >> 1) - oyb, wx = ((xq + 1) >> 1) - oxb;   // window coords of the (oy0, ox0) tap; the others are -1
-      const float wy0 = (y & 1) ? 0.125f : 0.375f, wx0 = (xq & 1) ? 0.125f : 0.375f;
-      const float wy1 = 0.5f - wy0, wx1 = 0.5f - wx0;
+    const float4 wr = wrow[y - ty0], wc = wcol[xq - tx0];
+    const int wy = ((y + 1) >> 1) - oyb, wx = ((xq + 1) >> 1) - oxb;   // window coords of the (oy0, ox0) tap
+    auto tap = [&](int dy, int dx, float w) {
       float v[UE];
-      unpack16<T>(win[(wy * WW + wx) * CVS + cvl], v);
+      unpack16<T>(win[((wy + dy) * WW + wx + dx) * CVS + cvl], v);
 #pragma unroll
-      for (int e = 0; e < UE; ++e) g[e] += wy0 * wx0 * v[e];
-      unpack16<T>(win[(wy * WW + wx - 1) * CVS + cvl], v);
-#pragma unroll
-      for (int e = 0; e < UE; ++e) g[e] += wy0 * wx1 * v[e];
-      unpack16<T>(win[((wy - 1) * WW + wx) * CVS + cvl], v);
-#pragma unroll
-      for (int e = 0; e < UE; ++e) g[e] += wy1 * wx0 * v[e];
-      unpack16<T>(win[((wy - 1) * WW + wx - 1) * CVS + cvl], v);
-#pragma unroll
-      for (int e = 0; e < UE; ++e) g[e] += wy1 * wx1 * v[e];
-    } else {
-      for (int ay = 0; ay < 4; ++ay) {
-        if ((ay == 1 && y != 1) || (ay == 2 && y != p.H - 2) || (ay == 3 && y != p.H - 3)) continue;
-        const int py = ay == 0 ? y : (ay == 1 ? -1 : (ay == 2 ? p.H : p.H + 1));
-        for (int ky = 0; ky < 4; ++ky) {
-          const int tyy = py + 1 - ky;
-          if (tyy < 0 || (tyy & 1) || (tyy >> 1) >= p.Ho) continue;
-          for (int ax = 0; ax < 4; ++ax) {
-            if ((ax == 1 && xq != 1) || (ax == 2 && xq != p.W - 2) || (ax == 3 && xq != p.W - 3)) continue;
-            const int px = ax == 0 ? xq : (ax == 1 ? -1 : (ax == 2 ? p.W : p.W + 1));
-            for (int kx = 0; kx < 4; ++kx) {
-              const int txx = px + 1 - kx;
-              if (txx < 0 || (txx & 1) || (txx >> 1) >= p.Wo) continue;
-              // every tap of every pixel of the tile lies inside the staged window: border pixels read LDS as well, so no global
-              // load sits in divergent code (hipcc would otherwise drain vmcnt(0) -- stores included -- at every pixel)
-              const int wyy = min(max((tyy >> 1) - oyb, 0), WH - 1), wxx = min(max((txx >> 1) - oxb, 0), WW - 1);
-              float v[UE];
-              unpack16<T>(win[(wyy * WW + wxx) * CVS + cvl], v);
-              const float w = blur_w(ky) * blur_w(kx);
-#pragma unroll
-              for (int e = 0; e < UE; ++e) g[e] += w * v[e];
-            }
-          }
-        }
-      }
+      for (int e = 0; e < UE; ++e) g[e] += w * v[e];
+    };
+    tap(-1, -1, wr.x * wc.x); tap(-1, 0, wr.x * wc.y); tap(0, -1, wr.y * wc.x); tap(0, 0, wr.y * wc.y);
+    if (wr.z != 0.f || wc.z != 0.f) {                              // only next to the bottom / right reflect border
+      tap(-1, 1, wr.x * wc.z); tap(0, 1, wr.y * wc.z);
+      tap(1, -1, wr.z * wc.x); tap(1, 0, wr.z * wc.y); tap(1, 1, wr.z * wc.z);
     }
     float xv[UE], xh[UE];
     unpack16<T>(xraw, xv);
@@ -502,6 +497,7 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
     }
   }
   if (MODE == 1 || (MODE == 0 && rstats)) {
+    __syncthreads();                                               // the window is dead: its LDS becomes the reduction scratch
 #pragma unroll
     for (int e = 0; e < UE; ++e) { red[threadIdx.x * UE + e] = a1[e]; red[256 * UE + threadIdx.x * UE + e] = a2[e]; }
     __syncthreads();
@@ -517,6 +513,144 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
       }
     }
   }
+}
+
+// Stride-1 blur of the up path (UNetUp: ConvTranspose2d -> BlurPool(stride 1) -> InstanceNorm, reference :118-134), forward and
+// transpose in one tiled kernel: no activation sits in front of this blur, so it is a pure depthwise [1,3,3,1]^2/64 filter with
+// reflect padding (1,2). A workgroup owns an 8 x 32 tile x (8 channel vectors): the (12 x 36)-pixel source window is staged once
+// in LDS (forward: reflect indexing at staging time; transpose: zero fill), and each thread runs the separable filter down one
+// column -- a horizontal pass per window row kept in a 5-deep register ring, then the vertical pass. Tap weights are tabulated
+// per tile row / column at offsets -2..+2 (forward uses -1..+2; the transpose -2..+1, plus +2 through the reflect aliases of the
+// bottom / right border), so border and interior pixels run the same code. STATS: InstanceNorm sums of the result.
+template <typename T, bool STATS>
+__global__ void __launch_bounds__(256)
+tfc_blur1_kernel(const ActParams p, const T* __restrict__ src, int src_pitch, T* __restrict__ dst, int dst_pitch, float* stats_out,
+                 int transpose, int tiles_x) {
+  constexpr int UE = ElemTraits<T>::UE;
+  constexpr int TH = 8, TW = 32, WH = TH + 4, WW = TW + 4, CVS = 8, PL = 256 / CVS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* win = reinterpret_cast<uint4*>(smem_raw);                // [WH][WW][CVS]
+  float* wrow = reinterpret_cast<float*>(smem_raw + (size_t)WH * WW * CVS * 16);   // [TH][8]
+  float* wcol = wrow + TH * 8;                                    // [TW][8]
+  float* red = reinterpret_cast<float*>(smem_raw);                // [2][256*UE] after the main loop
+  const int cvl = threadIdx.x % CVS, pl = threadIdx.x / CVS;
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.z * (CVS * UE);
+  const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+  const T* sn = src + (size_t)n * p.H * p.W * src_pitch + c0;
+  T* dn = dst + (size_t)n * p.H * p.W * dst_pitch + c0;
+  if (threadIdx.x < TH + TW) {
+    const bool isrow = threadIdx.x < TH;
+    const int q = isrow ? ty0 + threadIdx.x : tx0 + (threadIdx.x - TH);
+    const int L = isrow ? p.H : p.W;
+    float w5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (q < L) {
+      if (!transpose) {
+        w5[1] = 0.125f; w5[2] = 0.375f; w5[3] = 0.375f; w5[4] = 0.125f;
+      } else {
+        for (int a = 0; a < 4; ++a) {
+          if ((a == 1 && q != 1) || (a == 2 && q != L - 2) || (a == 3 && q != L - 3)) continue;
+          const int pq = a == 0 ? q : (a == 1 ? -1 : (a == 2 ? L : L + 1));
+          for (int k = 0; k < 4; ++k) {
+            const int o = pq + 1 - k;
+            if (o < 0 || o >= L) continue;
+            const int d = o - q + 2;
+            for (int j = 0; j < 5; ++j) if (j == d) w5[j] += blur_w(k);
+          }
+        }
+      }
+    }
+    float* t = isrow ? wrow + threadIdx.x * 8 : wcol + (threadIdx.x - TH) * 8;
+    for (int j = 0; j < 5; ++j) t[j] = w5[j];
+  }
+  for (int i = threadIdx.x; i < WH * WW * CVS; i += 256) {
+    const int cv = i % CVS, wp = i / CVS;
+    int y = ty0 - 2 + wp / WW, x = tx0 - 2 + wp % WW;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    bool ok;
+    if (!transpose) {                                              // reflect (1,2); positions beyond that carry zero weight
+      y = reflect_idx(y, p.H); x = reflect_idx(x, p.W);
+      ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+    } else {
+      ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+    }
+    if (ok) v = *reinterpret_cast<const uint4*>(sn + (size_t)(y * p.W + x) * src_pitch + cv * UE);
+    win[i] = v;
+  }
+  __syncthreads();
+  float a1[UE], a2[UE];
+#pragma unroll
+  for (int e = 0; e < UE; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+#pragma unroll 1
+  for (int lx = pl; lx < TW; lx += PL) {
+    const float4 wc03 = *reinterpret_cast<const float4*>(wcol + lx * 8);
+    const float wc4 = wcol[lx * 8 + 4];
+    const float wc[5] = {wc03.x, wc03.y, wc03.z, wc03.w, wc4};
+    const bool xin = tx0 + lx < p.W;
+    float ring[5][UE];
+#pragma unroll
+    for (int r = 0; r < WH; ++r) {
+      float h[UE];
+#pragma unroll
+      for (int e = 0; e < UE; ++e) h[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (wc[j] != 0.f) {
+          float v[UE];
+          unpack16<T>(win[(r * WW + lx + j) * CVS + cvl], v);
+#pragma unroll
+          for (int e = 0; e < UE; ++e) h[e] += wc[j] * v[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < UE; ++e) ring[r % 5][e] = h[e];
+      if (r >= 4) {
+        const int ly = r - 4;
+        const float4 wr03 = *reinterpret_cast<const float4*>(wrow + ly * 8);
+        const float wr4 = wrow[ly * 8 + 4];
+        float o[UE];
+#pragma unroll
+        for (int e = 0; e < UE; ++e)
+          o[e] = wr03.x * ring[(ly + 0) % 5][e] + wr03.y * ring[(ly + 1) % 5][e] + wr03.z * ring[(ly + 2) % 5][e] +
+                 wr03.w * ring[(ly + 3) % 5][e] + wr4 * ring[(ly + 4) % 5][e];
+        if (xin && ty0 + ly < p.H) {
+          const uint4 pk = pack16<T>(o);
+          if (STATS) {                                             // InstanceNorm sums of the fp32 result, as in the generic kernel
+#pragma unroll
+            for (int e = 0; e < UE; ++e) { a1[e] += o[e]; a2[e] += o[e] * o[e]; }
+          }
+          *reinterpret_cast<uint4*>(dn + (size_t)((ty0 + ly) * p.W + tx0 + lx) * dst_pitch + cvl * UE) = pk;
+        }
+      }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < UE; ++e) { red[threadIdx.x * UE + e] = a1[e]; red[256 * UE + threadIdx.x * UE + e] = a2[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CVS * UE; c += 256) {
+      float s1 = 0.f, s2 = 0.f;
+      const int ccv = c / UE, ce = c % UE;
+      for (int q = 0; q < PL; ++q) { s1 += red[(q * CVS + ccv) * UE + ce]; s2 += red[256 * UE + (q * CVS + ccv) * UE + ce]; }
+      atomicAdd(&stats_out[((size_t)n * p.C + c0 + c) * 2 + 0], s1);
+      atomicAdd(&stats_out[((size_t)n * p.C + c0 + c) * 2 + 1], s2);
+    }
+  }
+}
+template <typename T>
+static bool blur1_launch(const ActParams& p, const void* src, int src_pitch, void* dst, int dst_pitch, float* stats_out, int transpose,
+                         hipStream_t st) {
+  constexpr int UE = ElemTraits<T>::UE;
+  if (p.C % (8 * UE) != 0 || p.H < 4 || p.W < 4) return false;
+  const int tiles_x = (p.W + 31) / 32, tiles_y = (p.H + 7) / 8;
+  const dim3 grid(tiles_x * tiles_y, p.N, p.C / (8 * UE));
+  const size_t lds = (size_t)12 * 36 * 8 * 16 + (8 + 32) * 8 * sizeof(float);
+  if (stats_out)
+    hipLaunchKernelGGL((tfc_blur1_kernel<T, true>), grid, dim3(256), lds, st, p, (const T*)src, src_pitch, (T*)dst, dst_pitch, stats_out, transpose, tiles_x);
+  else
+    hipLaunchKernelGGL((tfc_blur1_kernel<T, false>), grid, dim3(256), lds, st, p, (const T*)src, src_pitch, (T*)dst, dst_pitch, stats_out, transpose, tiles_x);
+  return true;
 }
 
 // column sums: out[c] += sum over rows of x[row][c]   (bias gradients)
@@ -949,6 +1083,9 @@ static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stat
     hipLaunchKernelGGL((tfc_act_pool2_fwd_kernel<T>), g2, dim3(256), 0, st, p, (const T*)x, stats, (T*)out);
     return hipGetLastError();
   }
+  if (p.pool == 1 && !p.norm && p.slope == 1.f && !p.drop_thresh24 &&
+      blur1_launch<T>(p, x, p.x_pitch, out, p.o_pitch, stats_out, 0, st))        // pure blur of the up path: tiled kernel
+    return hipGetLastError();
   const dim3 grid = act_grid(p.Ho * p.Wo, p.C, ElemTraits<T>::UE, p.N);
   if (stats_out)
     hipLaunchKernelGGL((tfc_act_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)x, stats, (T*)out, stats_out);
@@ -978,7 +1115,9 @@ static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, cons
     if (p.C % cslice == 0 && 256 % (cslice / UE) == 0) {
       const int tiles_x = (p.W + 31) / 32, tiles_y = (p.H + 15) / 16;
       const dim3 grid(tiles_x * tiles_y, p.N, p.C / cslice);
-      const size_t lds = (size_t)11 * 19 * (cslice / UE) * 16 + 2 * 256 * UE * sizeof(float);
+      size_t lds = (size_t)11 * 19 * (cslice / UE) * 16;        // pooled-gradient window, reused as reduction scratch ...
+      if (lds < 2 * 256 * UE * sizeof(float)) lds = 2 * 256 * UE * sizeof(float);
+      lds += (16 + 32) * 16;                                      // ... + the per-row / per-column tap-weight tables
       if (mode == 0)                                              // mode 0 is only valid without normalisation, modes 1/2 only with it
         hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 0, false>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, dx_pitch, tiles_x, cslice);
       else if (mode == 1)
@@ -988,6 +1127,9 @@ static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, cons
       return hipGetLastError();
     }
   }
+  if (p.pool == 1 && mode == 0 && !use_x && !rstats && !p.drop_thresh24 &&
+      blur1_launch<T>(p, dout, p.o_pitch, dx, dx_pitch, nullptr, 1, st))          // transpose of the pure blur
+    return hipGetLastError();
   const dim3 grid = act_grid(p.H * p.W, p.C, ElemTraits<T>::UE, p.N);
   if (mode == 0) act_bwd_launch<T, 0>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
   else if (mode == 1) act_bwd_launch<T, 1>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
