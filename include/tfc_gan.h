@@ -68,8 +68,9 @@ int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int 
 /* ---- input gradient: dx = oscale * op^T(dy) (flags: TFC_EP_ACCUM) ------------------------------------------------ */
 int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
                    const void* packed, void* dx, int dx_pitch, const float* oscale, int flags);
-/* ---- weight gradient: dw (torch layout, fp32) = or += x (*) dy ; ws: tfc_conv_wgrad_ws_bytes() of scratch that must be
- *      ALL ZERO on entry (zero it once after allocation) and is left all zero on return ------------------------------ */
+/* ---- weight gradient: dw (torch layout, fp32) = or += x (*) dy ; ws: tfc_conv_wgrad_ws_bytes() of scratch = [64 MiB of split-K
+ *      slabs | fp32 accumulator]. Zero it once after allocation: the accumulator part must be ALL ZERO on entry and is left all
+ *      zero on return (the slab part is scratch). One buffer sized for the largest layer may be shared by every layer. ------- */
 size_t tfc_conv_wgrad_ws_bytes(int op, int Cin, int Cout);
 int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, const void* dy, int dy_pitch, int N, int H, int W,
                    int Cin, int Cout, void* ws, float* dw, int accumulate);

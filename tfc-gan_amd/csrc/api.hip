@@ -26,7 +26,7 @@ int tfc_nb32_padded(int nout);
 size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
-hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
+hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
 hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st);
 hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st);
@@ -439,7 +439,12 @@ extern "C" int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_
   return 0;
 }
 
-extern "C" size_t tfc_conv_wgrad_ws_bytes(int op, int Cin, int Cout) { (void)op; return (size_t)16 * Cin * Cout * sizeof(float); }
+// wgrad scratch = [split-K slabs | fp32 accumulator 16 x Cout x Cin]: at most 512 workgroups x 4 waves x 8 tiles x 4 KiB = 64 MiB of slabs.
+// The slabs come FIRST so that the accumulator (which must stay all-zero between calls) starts at the same offset for every layer
+// that shares one scratch buffer.
+static size_t wgrad_acc_bytes(int Cin, int Cout) { return (((size_t)16 * Cin * Cout * sizeof(float)) + 255) & ~(size_t)255; }
+static const size_t kWgradSlabBytes = (size_t)512 * 4 * 8 * 4 * 64 * 16;
+extern "C" size_t tfc_conv_wgrad_ws_bytes(int op, int Cin, int Cout) { (void)op; return wgrad_acc_bytes(Cin, Cout) + kWgradSlabBytes; }
 
 extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, const void* dy, int dy_pitch, int N, int H, int W,
                               int Cin, int Cout, void* ws, float* dw, int accumulate) {
@@ -450,16 +455,16 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
   if (int e = check_pitch(dt, dy_pitch, pad8(Cout), "dy")) return e;
   REQUIRE(ws != nullptr && dw != nullptr, "ws / dw null");
   hipStream_t st = (hipStream_t)stream;
-  WeightMap wm{};                                                // ws is all-zero on entry (caller zeroes it ONCE) and all-zero again on exit
+  WeightMap wm{};                                                // the accumulator part of ws is all-zero on entry (caller zeroes it ONCE) and again on exit
   {
     ProfScope prof(1, conv_flop(op, N, H, W, Cin, Cout), st);
     for (int ph = 0; ph < num_phases(op, 2); ++ph) {
       TfcGather d;
       if (int e = build_desc(op, 2, ph, N, H, W, Cin, Cout, x_pitch, dy_pitch, &d, &wm)) return e;
-      CHECK_HIP(tfc_launch_wgrad(dt, d, dy, x, (float*)ws, pad8(Cout), Cout, Cin, st), "tfc_conv_wgrad");
+      CHECK_HIP(tfc_launch_wgrad(dt, d, dy, x, (float*)((char*)ws + kWgradSlabBytes), ws, pad8(Cout), Cout, Cin, st), "tfc_conv_wgrad");
     }
   }
-  CHECK_HIP(tfc_launch_wgrad_finish((float*)ws, dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
+  CHECK_HIP(tfc_launch_wgrad_finish((float*)((char*)ws + kWgradSlabBytes), dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
   return 0;
 }
 

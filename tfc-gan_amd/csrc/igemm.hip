@@ -18,6 +18,7 @@
 //     byte geometry (a 16-byte unit = 8 bf16 = 4 fp32 channels);
 //   * epilogue fuses bias, InstanceNorm statistics (wave-shuffle + fp32 atomics), skip-gradient
 //     accumulation, and tanh + NCHW store for the generator head.
+#include <cstdlib>
 #include "common.h"
 #include "pack_math.h"
 
@@ -104,6 +105,15 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   const int nchunks = (d.Cin_pad * ES) / PB;
   const int nst = nchunks * d.nplanes;
 
+  // Phase stagger: the first wave of workgroups (3 per CU) would otherwise run in lockstep -- every CU in its main loop, then every CU
+  // in its store phase -- so the co-resident workgroups of a CU start a third of a tile time apart; later workgroups inherit it.
+  {
+    const int stag = flags >> 16;
+    if (stag && blockIdx.x < 768u) {
+      const int slot = blockIdx.x >> 8;
+      for (int i = 0; i < slot * stag; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+  }
   const int bid = tfc_xcd_remap(blockIdx.x, gridDim.x);
   const int nb_blk = bid % nblkN;
   int tile = bid / nblkN;
@@ -358,6 +368,174 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// weight-gradient GEMM for 2 x 2-tap planes (bf16): the sub-pixel phases of the transposed convolution and phase (0,0) of the
+// upsample-conv. With only four taps the generic kernel gives each wave ONE tap (3 transposing LDS reads per MFMA); here a
+// workgroup owns 64 n x 64 c and wave (nh, ch) owns the 32 n x 32 c quadrant for ALL four taps: the B fragments of halo rows
+// kt and kt+1 (column shifts 0 / 1) form a sliding register window, so a k-step costs 1 A + 2 new B fragments for 4 MFMAs
+// (1.5 reads per MFMA). Accumulator index = tap_dy * 2 + tap_dx (geometry); the flush maps it back to the filter taps.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+tfc_wgrad22_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restrict__ in, float* dwacc, float4* slab,
+                   int Nn_pad, int Nn_real, int Cw_real, int nbw, int ncb2, int nsplit) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROWB = 64;                                       // 32 channels x 2 bytes per LDS pixel row
+  constexpr int DO_BYTES = 2 * 128 * ROWB;
+  constexpr int NDO = 4, NHA = 5;                                // 16-byte units per thread: dO 1024, halo <= 2 * 9 * 17 * 4 = 1224
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nh = wave & 1, ch = wave >> 1;
+  const TfcPlane& pd = d.plane[0];
+  const int HP = pd.hh * pd.hw * ROWB;                           // bytes of one 32-channel halo plane
+  const int BUF_BYTES = DO_BYTES + 2 * HP;
+
+  const int bid = tfc_xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % (nbw * ncb2);
+  const int sp = bid / (nbw * ncb2);
+  const int cb = pair % ncb2, nb = pair / ncb2;
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+
+  f32x16_t acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
+
+  uint4 vdo[NDO], vha[NHA];
+  const int nunits = pd.hh * pd.hw * 4;                          // per halo plane
+  auto tile_load = [&](int tl) {
+    int t = tl;
+    const int txb = t % d.tiles_x; t /= d.tiles_x;
+    const int tyb = t % d.tiles_y;
+    const int img = t / d.tiles_y;
+    const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) {
+      const int idx = tid + i * 256;
+      const int g = idx & 3, px = (idx >> 2) & 127, ni = idx >> 9;
+      const int a = a0 + (px >> 4), b = b0 + (px & 15);
+      const int n0 = nb * 64 + ni * 32 + g * 8;
+      vdo[i] = make_uint4(0, 0, 0, 0);
+      if (a < d.GH && b < d.GW && n0 < Nn_pad) {
+        const int oy = a * d.OS + d.OOY, ox = b * d.OS + d.OOX;
+        vdo[i] = *reinterpret_cast<const uint4*>(dO + ((size_t)(img * d.OH + oy) * d.OW + ox) * d.out_pitch + n0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;
+      vha[i] = make_uint4(0, 0, 0, 0);
+      if (idx < 2 * nunits) {
+        const int half = idx >= nunits ? 1 : 0;
+        const int u = idx - half * nunits;
+        const int g = u & 3, pix = u >> 2;
+        const int hy = pix / pd.hw, hx = pix - hy * pd.hw;
+        const int y = (a0 + pd.dy0 + hy) * d.SS + pd.py;
+        const int x = (b0 + pd.dx0 + hx) * d.SS + pd.px;
+        const int c0 = (cb * 2 + half) * 32 + g * 8;
+        if (y >= 0 && y < d.IH && x >= 0 && x < d.IW && c0 < d.Cin_pad)
+          vha[i] = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch + c0);
+      }
+    }
+  };
+  auto tile_store = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) *reinterpret_cast<uint4*>(buf + (tid + i * 256) * 16) = vdo[i];   // [ni][px][32 n]
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;                             // == (half * hh*hw + pix) * 4 + g : the LDS image order
+      if (idx < 2 * nunits) *reinterpret_cast<uint4*>(buf + DO_BYTES + idx * 16) = vha[i];
+    }
+  };
+
+  const bool active = (Nn_pad - nb * 64) > nh * 32 && (cb * 2 + ch) * 32 < d.Cin_pad;   // quadrant outside the real tensor: no MFMAs
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trLane = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;
+  auto tr16 = [&](const unsigned char* p0) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + 4 * ROWB));
+    uint4 r;
+    r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  };
+  auto compute = [&](const unsigned char* buf) {
+    if (!active) return;
+    const unsigned char* acol = buf + nh * 128 * ROWB + trLane;
+    const unsigned char* hcol = buf + DO_BYTES + ch * HP + trLane;
+    const int rowb = pd.hw * ROWB;
+    uint4 b0[2], b1[2];
+    b0[0] = tr16(hcol);
+    b0[1] = tr16(hcol + ROWB);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      b1[0] = tr16(hcol + (kt + 1) * rowb);
+      b1[1] = tr16(hcol + (kt + 1) * rowb + ROWB);
+      const uint4 a = tr16(acol + kt * 16 * ROWB);
+      const bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b0[0]), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b0[1]), acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b1[0]), acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b1[1]), acc[3], 0, 0, 0);
+      b0[0] = b1[0]; b0[1] = b1[1];
+    }
+  };
+
+  int tl = sp;
+  int cur = 0;
+  if (tl < ntiles) { tile_load(tl); tile_store(smem); }
+  __syncthreads();
+  for (; tl < ntiles; tl += nsplit) {
+    const bool more = (tl + nsplit) < ntiles;
+    if (more) tile_load(tl + nsplit);
+    compute(smem + cur * BUF_BYTES);
+    if (more) tile_store(smem + (cur ^ 1) * BUF_BYTES);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if (!active) return;
+  if (TFC_ABL == 11) {
+    float chk = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) chk += acc[a][j];
+    if (chk != 12345.678f) return;
+  }
+  if (slab) {                                                    // split-K partial -> this workgroup's slab, register order (see tfc_wgrad_reduce_kernel)
+    float4* ps = slab + ((size_t)bid * 4 + wave) * (4 * 4 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        ps[(a * 4 + q4) * 64] = make_float4(acc[a][4 * q4], acc[a][4 * q4 + 1], acc[a][4 * q4 + 2], acc[a][4 * q4 + 3]);
+    return;
+  }
+  const int c = (cb * 2 + ch) * 32 + (lane & 31);
+  const int hrow = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    int mask = 0;
+    for (int t = 0; t < 4; ++t)
+      if (pd.tap_dy[t] == (a >> 1) && pd.tap_dx[t] == (a & 1)) mask = pd.tap_mask[t];
+    for (int m = mask; m; m &= m - 1) {
+      const int slot = __ffs(m) - 1;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int n = nb * 64 + nh * 32 + (j & 3) + 8 * (j >> 2) + 4 * hrow;
+        if (n < Nn_real && c < Cw_real) atomicAdd(&dwacc[((size_t)slot * Nn_real + n) * Cw_real + c], acc[a][j]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight-gradient GEMM:  dWacc[slot][n][c] += sum_pixels dO[pixel][n] * in[src(pixel, tap)][c]
 //   rows = n (64 per workgroup = 2 MFMA row blocks), cols = c (32 per workgroup), K = the 128 pixels of a tile;
 //   wave w owns taps {w*TPW .. w*TPW+TPW-1}; a workgroup walks a strided subset of the pixel tiles (split-K) and
@@ -372,7 +550,7 @@ template <typename T> struct WgradFrag;
 //   window needs ONE new fragment per k-step instead of four.
 template <typename T, int TPW, bool RASTER>
 __global__ void __launch_bounds__(256, 2)
-tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restrict__ in, float* dwacc,
+tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restrict__ in, float* dwacc, float4* slab,
                  int Nn_pad, int Nn_real, int Cw_real, int nbw, int ncb, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = sizeof(T);
@@ -574,6 +752,27 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
   }
 
   // ---- flush ----
+  if (TFC_ABL == 11) {
+    float chk = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) chk += acc[ti][ni][j];
+    if (chk != 12345.678f) return;
+  }
+  if (slab) {                                                    // split-K partial -> this workgroup's slab, register order (see tfc_wgrad_reduce_kernel)
+    float4* ps = slab + ((size_t)bid * 4 + wave) * (TPW * 2 * 4 * 64) + lane;
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          ps[((ti * 2 + ni) * 4 + q4) * 64] = make_float4(acc[ti][ni][4 * q4], acc[ti][ni][4 * q4 + 1], acc[ti][ni][4 * q4 + 2], acc[ti][ni][4 * q4 + 3]);
+    return;
+  }
   const int c = cb * 32 + (lane & 31);
   const int hrow = lane >> 5;
 #pragma unroll
@@ -663,6 +862,61 @@ hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int 
   if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_pack_planned_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
   else hipLaunchKernelGGL((tfc_pack_planned_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
   return hipGetLastError();
+}
+
+// Split-K reduction of the weight-gradient slabs. fp32 atomics run at ~1.3 TB/s on this chip (they execute at the memory side) and a
+// one-round wgrad launch flushes the WHOLE chip's accumulator state (~67 MB): ~50 us of a ~130 us kernel. Instead every workgroup
+// stores its accumulators, in register order, with plain 16-byte stores (~6 TB/s): slab[workgroup = sp*npairs + pair][wave][tile a][q][lane]
+// = float4 of accumulator registers 4q..4q+3.  This kernel sums the nsplit slabs of one 64-lane row (one workgroup per row, its four
+// waves take every fourth split, LDS combine) and adds the result to acc[slot][n][c] -- one thread per element, no atomics.
+//   kind 0 (tfc_wgrad_kernel):   wave = tap % 4, tile a = (tap / 4) * 2 + ni;     n = nb*64 + ni*32 + row, c = cb*32 + (lane & 31)
+//   kind 1 (tfc_wgrad22_kernel): wave = ch*2 + nh, tile a = tap_dy*2 + tap_dx;     n = nb*64 + nh*32 + row, c = (cb*2+ch)*32 + (lane & 31)
+//   row of register j = 4q+e in lane l:  e + 8q + 4*(l >> 5)
+__global__ void __launch_bounds__(256)
+tfc_wgrad_reduce_kernel(const float4* __restrict__ slab, float* acc, const TfcPlane pd, int kind, int T, int nsplit, int npairs, int ncbx,
+                        int Nn_real, int Cw_real) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  int rowid = blockIdx.x;                                        // ((pair * 4 + wave) * T + a) * 4 + q
+  const int q = rowid & 3; rowid >>= 2;
+  const int a = rowid % T; rowid /= T;
+  const int wave = rowid & 3;
+  const int pair = rowid >> 2;
+  const size_t blk_units = (size_t)4 * T * 4 * 64;
+  const float4* p0 = slab + ((size_t)pair * 4 + wave) * (T * 4 * 64) + (a * 4 + q) * 64 + lane;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int sp = k; sp < nsplit; sp += 4) {
+    const float4 v = p0[(size_t)sp * npairs * blk_units];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  part[k][lane] = s;
+  __syncthreads();
+  if (k != 0) return;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) { const float4 v = part[i][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  const int cbx = pair % ncbx, nb = pair / ncbx;
+  int mask = 0, n0, c;
+  if (kind == 0) {
+    const int tap = (a >> 1) * 4 + wave;
+    if (tap < pd.ntaps) mask = pd.tap_mask[tap];
+    n0 = nb * 64 + (a & 1) * 32;
+    c = cbx * 32 + (lane & 31);
+  } else {
+    for (int t = 0; t < 4; ++t)
+      if (pd.tap_dy[t] == (a >> 1) && pd.tap_dx[t] == (a & 1)) mask = pd.tap_mask[t];
+    n0 = nb * 64 + (wave & 1) * 32;
+    c = (cbx * 2 + (wave >> 1)) * 32 + (lane & 31);
+  }
+  n0 += 8 * q + 4 * (lane >> 5);
+  if (c >= Cw_real) return;
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+  for (int m = mask; m; m &= m - 1) {
+    const int slot = __ffs(m) - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n0 + e < Nn_real) acc[((size_t)slot * Nn_real + n0 + e) * Cw_real + c] += sv[e];
+  }
 }
 
 // fp32 accumulator [16 slots][Nn][Cw] -> torch-layout gradient  grad[n*sn + c*sc + slot]
@@ -755,6 +1009,9 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
   }
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1);
   const long long phase_wbytes = (long long)tfc_packed_bytes(d, ES);
+  static int stag_env = -1;
+  if (stag_env < 0) { const char* e = getenv("TFC_STAGGER"); stag_env = e ? atoi(e) : 0; }
+  if (ntiles * nblkN > 768) flags |= stag_env << 16;
   hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
                      (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes);
   return hipGetLastError();
@@ -802,7 +1059,7 @@ hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const vo
 }
 
 template <typename T>
-static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad, int Nn_real,
+static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void* in, float* dwacc, float4* slab, int Nn_pad, int Nn_real,
                                  int Cw_real, hipStream_t st) {
   constexpr int ES = sizeof(T);
   const int nbw = (Nn_pad + 63) / 64, ncb = (d.Cin_pad + 31) / 32;
@@ -814,20 +1071,46 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   if (nsplit < 1) nsplit = 1;
   const int lds = (2 * 128 * 32 * ES + TFC_MAX_HH * TFC_MAX_HW * 32 * ES) * (ES == 2 ? 2 : 1);
   const dim3 grid(nbw * ncb * nsplit);
+  if constexpr (ES == 2) {
+    bool t22 = d.plane[0].ntaps == 4 && g_tfc_force_cfg != 2;
+    int seen = 0;
+    for (int t = 0; t < 4 && t22; ++t) {
+      t22 = (unsigned)d.plane[0].tap_dy[t] < 2u && (unsigned)d.plane[0].tap_dx[t] < 2u;
+      seen |= 1 << (d.plane[0].tap_dy[t] * 2 + d.plane[0].tap_dx[t]);
+    }
+    if (t22 && seen == 15) {                                     // 2 x 2-tap plane: quadrant-per-wave kernel (64 n x 64 c per workgroup)
+      const int ncb2 = (d.Cin_pad + 63) / 64;
+      int ns = 512 / (nbw * ncb2);
+      if (ns > ntiles) ns = ntiles;
+      if (ns < 1) ns = 1;
+      const int lds22 = 2 * (2 * 128 * 64 + 2 * d.plane[0].hh * d.plane[0].hw * 64);
+      hipLaunchKernelGGL((tfc_wgrad22_kernel<T>), dim3(nbw * ncb2 * ns), dim3(256), lds22, st, d, (const T*)dO, (const T*)in, dwacc, slab,
+                         Nn_pad, Nn_real, Cw_real, nbw, ncb2, ns);
+      if (slab)
+        hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb2 * 4 * 4 * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 1, 4, ns, nbw * ncb2,
+                           ncb2, Nn_real, Cw_real);
+      return hipGetLastError();
+    }
+  }
   const int tpw = (d.plane[0].ntaps + 3) / 4;                    // taps per wave (tap t belongs to wave t % 4)
   bool raster = (ES == 2) && d.plane[0].ntaps == 16;
   for (int t = 0; t < 16 && raster; ++t) raster = d.plane[0].tap_dy[t] == (t >> 2) && d.plane[0].tap_dx[t] == (t & 3);
-#define TFC_WG(TPW_, R_) hipLaunchKernelGGL((tfc_wgrad_kernel<T, TPW_, R_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, \
+#define TFC_WG(TPW_, R_) hipLaunchKernelGGL((tfc_wgrad_kernel<T, TPW_, R_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, slab, \
                                             Nn_pad, Nn_real, Cw_real, nbw, ncb, nsplit)
+  int tw = 4;
   if (raster) TFC_WG(4, true);
-  else if (tpw <= 1) TFC_WG(1, false); else if (tpw == 2) TFC_WG(2, false); else if (tpw == 3) TFC_WG(3, false); else TFC_WG(4, false);
+  else if (tpw <= 1) { tw = 1; TFC_WG(1, false); } else if (tpw == 2) { tw = 2; TFC_WG(2, false); } else if (tpw == 3) { tw = 3; TFC_WG(3, false); } else TFC_WG(4, false);
 #undef TFC_WG
+  if (slab)
+    hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * (tw * 2) * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 0, tw * 2, nsplit,
+                       nbw * ncb, ncb, Nn_real, Cw_real);
   return hipGetLastError();
 }
-hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, int Nn_pad,
+// slab: >= TFC_WGRAD_SLAB_BYTES of scratch for the split-K partials (bf16 path); nullptr = flush with fp32 atomics (fp32 parity mode)
+hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad,
                             int Nn_real, int Cw_real, hipStream_t st) {
-  return dt == TFC_DT_BF16 ? launch_wgrad_t<bf16_t>(d, dO, in, dwacc, Nn_pad, Nn_real, Cw_real, st)
-                           : launch_wgrad_t<float>(d, dO, in, dwacc, Nn_pad, Nn_real, Cw_real, st);
+  return dt == TFC_DT_BF16 ? launch_wgrad_t<bf16_t>(d, dO, in, dwacc, (float4*)slab, Nn_pad, Nn_real, Cw_real, st)
+                           : launch_wgrad_t<float>(d, dO, in, dwacc, nullptr, Nn_pad, Nn_real, Cw_real, st);
 }
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
                                    int accumulate, hipStream_t st) {

@@ -152,7 +152,8 @@ def conv_dgrad(dt, op, dy: View, N, H, W, Cin, Cout, packed, dx: View, accumulat
 def conv_wgrad(dt, op, x: View, dy: View, Cin, Cout, dw, accumulate=False, ws=None):
     nbytes = lib().tfc_conv_wgrad_ws_bytes(op, Cin, Cout)
     if ws is None or ws.numel() * ws.element_size() < nbytes:
-        ws = torch.zeros(max(nbytes, 16 * 1024 * 512 * 4), dtype=torch.uint8, device=x.t.device)   # zero ONCE: the kernels re-zero it
+        nbig = lib().tfc_conv_wgrad_ws_bytes(op, 1024, 512)       # the largest layer of the path, so one buffer serves every call
+        ws = torch.zeros(max(nbytes, nbig), dtype=torch.uint8, device=x.t.device)   # zero ONCE: the kernels re-zero the accumulator
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     check(lib().tfc_conv_wgrad(stream_ptr(), dt, op, x.ptr, x.pitch, dy.ptr, dy.pitch, x.N, x.H, x.W, Cin, Cout, _p(ws), _p(dw),
                                1 if accumulate else 0), "tfc_conv_wgrad")
