@@ -82,3 +82,21 @@ if "wgrad" in which:
         ops.conv_wgrad(dt, ops.OP_CONV, x3, gy3, 256, 512, dw3)
 torch.cuda.synchronize()
 print("done")
+if "cfg4" in which:
+    import time
+    lib = T._lib.load()
+    shapes = [(128, 64, 128), (64, 128, 256), (32, 256, 512)]
+    for H, Cin, Cout in shapes:
+        x = rnd(N, H, H, Cin); w = torch.randn(Cout, Cin, 4, 4, device=DEV) * 0.03; y = ops.new_act(N, H - 1, H - 1, Cout, dt, DEV)
+        pk = ops.pack_weight(dt, ops.OP_CONV, 0, w, Cin, Cout)
+        for cfg in (0, 4):
+            lib.tfc_debug_set_igemm_config(cfg)
+            for _ in range(2):
+                ops.conv_fwd(dt, ops.OP_CONV, x, Cin, Cout, pk, y)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10):
+                ops.conv_fwd(dt, ops.OP_CONV, x, Cin, Cout, pk, y)
+            torch.cuda.synchronize(); dtm = (time.perf_counter() - t0) / 10
+            fl = 2.0 * N * (H - 1) ** 2 * Cin * Cout * 16
+            print(f"H={H} {Cin}->{Cout} cfg {cfg}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
+    lib.tfc_debug_set_igemm_config(-1)

@@ -75,9 +75,6 @@ template <> struct TapPat<6> : TapPatRC<3, 3, false> {};
 #ifndef TFC_MINW
 #define TFC_MINW 3
 #endif
-#ifndef TFC_ABL
-#define TFC_ABL 0            // development-only ablation switch for the diagnostic builds of scripts/ablate.sh (0 in the product)
-#endif
 template <typename T, int MT, int NT, int WM, int WN, int PAT>
 __global__ void __launch_bounds__(256, TFC_MINW)
 tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __restrict__ wp, T* out,
@@ -105,15 +102,6 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   const int nchunks = (d.Cin_pad * ES) / PB;
   const int nst = nchunks * d.nplanes;
 
-  // Phase stagger: the first wave of workgroups (3 per CU) would otherwise run in lockstep -- every CU in its main loop, then every CU
-  // in its store phase -- so the co-resident workgroups of a CU start a third of a tile time apart; later workgroups inherit it.
-  {
-    const int stag = flags >> 16;
-    if (stag && blockIdx.x < 768u) {
-      const int slot = blockIdx.x >> 8;
-      for (int i = 0; i < slot * stag; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-  }
   const int bid = tfc_xcd_remap(blockIdx.x, gridDim.x);
   const int nb_blk = bid % nblkN;
   int tile = bid / nblkN;
@@ -188,9 +176,9 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
     halo_store(smem);
     __syncthreads();
     int gs = 0;
-    for (int st = 0; st < (TFC_ABL == 6 ? 0 : nst); ++st) {
+    for (int st = 0; st < nst; ++st) {
       const bool more = (st + 1) < nst;
-      if (more && TFC_ABL < 4) halo_load(st + 1);
+      if (more) halo_load(st + 1);
       const unsigned char* buf = smem + (st & 1) * buf_bytes + laneBase;
 #pragma unroll 1
       for (int row = 0; row < TapPat<PAT>::ROWS; ++row) {
@@ -200,7 +188,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         for (int mi = 0; mi < MT; ++mi) a[0][mi] = *reinterpret_cast<const uint4*>(rbuf + TapPat<PAT>::dx(0) * 80 + mi * (2 * P * 80));
 #pragma unroll
         for (int s = 0; s < NSR; ++s) {
-          if (s + 1 < NSR && !(TFC_ABL & 2) && TFC_ABL < 4) {   // A fragments one k-substep ahead
+          if (s + 1 < NSR) {                                     // A fragments one k-substep ahead
             const int off = TapPat<PAT>::dx((s + 1) >> 1) * 80 + ((s + 1) & 1) * 32;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) a[(s + 1) & 1][mi] = *reinterpret_cast<const uint4*>(rbuf + off + mi * (2 * P * 80));
@@ -208,14 +196,14 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[(TFC_ABL & 2) || TFC_ABL >= 4 ? 0 : (s & 1)][mi], br[s % BD][nt], acc[mi][nt]);
-          if (!(TFC_ABL & 1) && TFC_ABL < 4) loadB(gs + s + BD, br[s % BD]);   // weights BD k-substeps ahead
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[s & 1][mi], br[s % BD][nt], acc[mi][nt]);
+          loadB(gs + s + BD, br[s % BD]);                        // weights BD k-substeps ahead
           asm volatile("" ::: "memory");                         // keep the issue order: hipcc otherwise sinks the prefetch to its use
         }
         gs += NSR;
       }
-      if (more && TFC_ABL < 4) halo_store(smem + ((st + 1) & 1) * buf_bytes);
-      if (TFC_ABL < 5) __syncthreads();
+      if (more) halo_store(smem + ((st + 1) & 1) * buf_bytes);
+      __syncthreads();
     }
   } else {
     uint4 b0r[NT], b1r[NT];
@@ -271,16 +259,6 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   }
 
   // ---- epilogue ----
-  if (TFC_ABL == 7) {
-    float chk = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) chk += acc[mi][nt][j];
-    if (chk != 12345.678f) return;
-  }
   const float* bias_p = (flags & TFC_EP_BIAS) ? bias : nullptr;
   const float osc = oscale ? *oscale : 1.f;                      // spectral norm: conv(x, W / sigma) = conv(x, W) / sigma
   constexpr bool STAGED = (ES == 2);                             // bf16: transpose through LDS, store whole 16-byte units
@@ -303,7 +281,6 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         float v = acc[mi][nt][j] * osc + bv;
         if (STAGED && !(flags & TFC_EP_TANH_NCHW)) {
           if (ok) { s1 += v; s2 += v * v; }
-          if (TFC_ABL != 9 || v == 12345.678f)
           *reinterpret_cast<bf16_t*>(smem + (ty * TFC_TILE_W + tx) * ROWP + ((wn * NT + nt) * 32 + r) * 2) = f32_to_bf16(v);
         } else if (ok) {
           const int oy = a * d.OS + d.OOY + phy * d.ph_oo, ox = b * d.OS + d.OOX + phx * d.ph_oo;
@@ -350,7 +327,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
             for (int e = 0; e < 8; ++e) f[e] += g[e];
             v = pack16<bf16_t>(f);
           }
-          if (TFC_ABL != 8 || v.x == 0x12345678u) store_stream16(po, v);
+          store_stream16(po, v);
         } else {                                                 // ragged tail (Nout not a multiple of 8): element stores
           float f[8];
           unpack16<bf16_t>(v, f);
@@ -500,14 +477,6 @@ tfc_wgrad22_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restr
   }
 
   if (!active) return;
-  if (TFC_ABL == 11) {
-    float chk = 0.f;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) chk += acc[a][j];
-    if (chk != 12345.678f) return;
-  }
   if (slab) {                                                    // split-K partial -> this workgroup's slab, register order (see tfc_wgrad_reduce_kernel)
     float4* ps = slab + ((size_t)bid * 4 + wave) * (4 * 4 * 64) + lane;
 #pragma unroll
@@ -752,16 +721,6 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
   }
 
   // ---- flush ----
-  if (TFC_ABL == 11) {
-    float chk = 0.f;
-#pragma unroll
-    for (int ti = 0; ti < TPW; ++ti)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) chk += acc[ti][ni][j];
-    if (chk != 12345.678f) return;
-  }
   if (slab) {                                                    // split-K partial -> this workgroup's slab, register order (see tfc_wgrad_reduce_kernel)
     float4* ps = slab + ((size_t)bid * 4 + wave) * (TPW * 2 * 4 * 64) + lane;
 #pragma unroll
@@ -1009,9 +968,6 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
   }
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1);
   const long long phase_wbytes = (long long)tfc_packed_bytes(d, ES);
-  static int stag_env = -1;
-  if (stag_env < 0) { const char* e = getenv("TFC_STAGGER"); stag_env = e ? atoi(e) : 0; }
-  if (ntiles * nblkN > 768) flags |= stag_env << 16;
   hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
                      (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes);
   return hipGetLastError();

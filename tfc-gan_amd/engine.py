@@ -71,6 +71,7 @@ class TrainStep:
             neg_idx = parallel.shared_neg_idx(t, self.seed)
         drop_seed = (self.seed * 7919 + t * 104729 + parallel.rank() * 1299709) & 0x3FFFFFF
         train = self.G_mod.training
+        ops.arena_begin(self.dev)                                 # one fill for all the small zero-initialised buffers of this step
         # ---------------- generator step ----------------
         fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
         pf, dctx_f = self.D.forward(fake, real_A, power_iter=True, save=True)
@@ -101,6 +102,7 @@ class TrainStep:
         dscale = self.d_reduce.finish()
         ops.adam_step(self.dflat.data, self.dflat.grad, self.dm, self.dv, self.lr, self.b1, self.b2, self.eps, t, dscale)
         self.D.repack()
+        ops.arena_end(self.dev)
         loss_g = self.lambda_gan * loss_gan + loss_trip + self.lambda_fft * loss_fft
         loss_temp = None
         if T_B is not None:

@@ -120,7 +120,7 @@ class GeneratorCore:
         for i, (name, cin, cout, normalize, drop) in enumerate(G_DOWN):
             h = cur.H
             raw = new_act(N, h - 1, h - 1, cout, dt, dev)
-            stats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev) if normalize else None
+            stats = ops.zeros_f32((N, cout, 2), dev) if normalize else None
             ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.packed[name]["fwd"], raw, stats=stats)
             if i < 5:
                 up = skip_of[i]
@@ -139,7 +139,7 @@ class GeneratorCore:
             rawT = new_act(N, 2 * h, 2 * h, cout, dt, dev)
             ops.conv_fwd(dt, OP_CONVT, cur, cin, cout, self.packed[name]["fwd"], rawT)
             blur = new_act(N, 2 * h, 2 * h, cout, dt, dev)
-            bstats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
+            bstats = ops.zeros_f32((N, cout, 2), dev)
             ops.act_fwd(dt, rawT, blur, stats=None, slope=1.0, pool=1, stats_out=bstats)
             ops.act_fwd(dt, blur, cat[name].sub(0, cout), stats=bstats, slope=0.0, pool=0, drop_p=drop if train else 0.0,
                         seed=seed * 64 + 16 + j)
@@ -183,7 +183,7 @@ class GeneratorCore:
             H = blur.H
             g_out = g_cat.sub(0, cout)
             g_skip[skip] = g_cat.sub(cout, g_cat.pitch - cout)
-            rstats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
+            rstats = ops.zeros_f32((N, cout, 2), dev)
             dp = drop if ctx.train else 0.0
             sd = ctx.seed * 64 + 16 + j
             ops.act_bwd(dt, 1, g_out, blur, N, H, H, cout, None, stats=bstats, slope=0.0, pool=0, drop_p=dp, seed=sd, rstats=rstats)
@@ -209,7 +209,7 @@ class GeneratorCore:
             sd = ctx.seed * 64 + i
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             if normalize:
-                rstats = torch.zeros((N, cout, 2), dtype=torch.float32, device=dev)
+                rstats = ops.zeros_f32((N, cout, 2), dev)
                 ops.act_bwd(dt, 1, g_cur, raw, N, Hc, Hc, cout, None, stats=stats, slope=0.2, pool=2, drop_p=dp, seed=sd, rstats=rstats)
                 ops.act_bwd(dt, 2, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=stats, slope=0.2, pool=2, drop_p=dp, seed=sd, rstats=rstats)
             else:
@@ -320,7 +320,7 @@ class DiscriminatorCore:
             u, v, sigma2 = ctx.sn[bi]
             Hc = raw.H
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
-            gb_img = torch.zeros((N, cout), dtype=torch.float32, device=dev) if grads is not None else None
+            gb_img = ops.zeros_f32((N, cout), dev) if grads is not None else None
             ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
             W = self.params[f"model.{i}.parametrizations.weight.original"]
             if grads is not None:

@@ -74,6 +74,59 @@ class View:
         return View(self.t, C, self.coff + coff)
 
 
+class ZeroArena:
+    """Small zero-initialised fp32 scratch (InstanceNorm statistics, bias-gradient partials, loss scalars) for one training step:
+    ONE fill per step instead of one torch.zeros launch per buffer (~33 per step). `begin()` re-zeroes the part handed out since
+    the previous begin(); views stay valid until the next begin() -- i.e. for the rest of the step that took them."""
+
+    def __init__(self, device, nfloats=1 << 20):
+        self.buf = torch.zeros(nfloats, dtype=torch.float32, device=device)
+        self.used = 0
+        self.active = False
+
+    def begin(self):
+        if self.used:
+            self.buf[:self.used].zero_()
+        self.used = 0
+        self.active = True
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n4 = (n + 63) // 64 * 64                                  # 256-byte granules: every view stays 16-byte aligned
+        if self.used + n4 > self.buf.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=self.buf.device)
+        v = self.buf[self.used:self.used + n].view(shape)
+        self.used += n4
+        return v
+
+
+_ARENA = {}
+
+
+def arena_begin(device):
+    """start a step: from now on zeros_f32() on this device is served from the step arena"""
+    dev = torch.device(device)
+    a = _ARENA.get(dev)
+    if a is None:
+        a = _ARENA[dev] = ZeroArena(dev)
+    a.begin()
+    return a
+
+
+def arena_end(device):
+    """end of the step: later zeros_f32() calls (module-level forward / backward outside TrainStep) get buffers of their own"""
+    a = _ARENA.get(torch.device(device))
+    if a is not None:
+        a.active = False
+
+
+def zeros_f32(shape, device):
+    a = _ARENA.get(torch.device(device))
+    return a.take(tuple(shape)) if a is not None and a.active else torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def new_act(N, H, W, C, dt, device, zero=False):
     f = torch.zeros if zero else torch.empty
     return View(f((N, H, W, C), dtype=torch_dtype(dt), device=device), C)
