@@ -100,3 +100,31 @@ if "cfg4" in which:
             fl = 2.0 * N * (H - 1) ** 2 * Cin * Cout * 16
             print(f"H={H} {Cin}->{Cout} cfg {cfg}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
     lib.tfc_debug_set_igemm_config(-1)
+if "overlap" in which:
+    # do two latency-bound MFMA kernels co-run faster than back to back? conv fwd/dgrad chain on one stream, wgrad on another
+    import time
+    x = rnd(N, 128, 128, 64); w = torch.randn(128, 64, 4, 4, device=DEV) * 0.03; y = ops.new_act(N, 127, 127, 128, dt, DEV)
+    pk = ops.pack_weight(dt, ops.OP_CONV, 0, w, 64, 128); pkd = ops.pack_weight(dt, ops.OP_CONV, 1, w, 64, 128)
+    gy = rnd(N, 127, 127, 128); gx = ops.new_act(N, 128, 128, 64, dt, DEV)
+    dw = torch.empty(128, 64, 4, 4, device=DEV)
+    raw = rnd(N, 255, 255, 64); dxv = ops.new_act(N, 255, 255, 64, dt, DEV); gpool = rnd(N, 128, 128, 64)
+    ws = ops.conv_wgrad(dt, ops.OP_CONV, x, gy, 64, 128, dw)
+    s2 = torch.cuda.Stream()
+    def seq():
+        ops.conv_dgrad(dt, ops.OP_CONV, gy, N, 128, 128, 64, 128, pkd, gx)
+        ops.act_bwd(dt, 0, gpool, raw, N, 255, 255, 64, dxv, slope=0.2, pool=2)
+        ops.conv_wgrad(dt, ops.OP_CONV, x, gy, 64, 128, dw, ws=ws)
+    def par():
+        ev = torch.cuda.Event(); ev.record()
+        with torch.cuda.stream(s2):
+            s2.wait_event(ev)
+            ops.conv_wgrad(dt, ops.OP_CONV, x, gy, 64, 128, dw, ws=ws)
+            ev2 = torch.cuda.Event(); ev2.record()
+        ops.conv_dgrad(dt, ops.OP_CONV, gy, N, 128, 128, 64, 128, pkd, gx)
+        ops.act_bwd(dt, 0, gpool, raw, N, 255, 255, 64, dxv, slope=0.2, pool=2)
+        torch.cuda.current_stream().wait_event(ev2)
+    for name, fn in (("sequential", seq), ("two streams", par), ("sequential", seq), ("two streams", par)):
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); print(f"{name}: {(time.perf_counter() - t0) / 20 * 1e6:8.1f} us per (dgrad + act_bwd + wgrad)")
