@@ -139,6 +139,25 @@ def test_conv_family(op, N, H, W, Cin, Cout, dt, cfg, force_cfg):
     assert (dw.cpu() - 2 * gw).abs().max().item() <= 2 * wtol
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,with_bias", [(2, 33, 18, 3, 64, False), (1, 40, 70, 6, 64, True), (6, 256, 256, 6, 64, True),
+                                                       (5, 200, 256, 3, 64, False)])
+def test_first_layer_weights_stationary_kernel(N, H, W, Cin, Cout, with_bias):
+    """bf16, 8 padded input channels, no statistics: the persistent weights-stationary kernel (several tiles per workgroup at the
+    big sizes) against torch on bf16-rounded operands; 1/sigma (oscale) and bias in the epilogue"""
+    dt = DT_BF16
+    x = q(rnd((N, Cin, H, W), 5), dt)
+    w = rnd((Cout, Cin, 4, 4), 6, 1.0 / np.sqrt(Cin * 16))
+    b = rnd((Cout,), 7, 0.5) if with_bias else None
+    osc = 0.37
+    want = F.conv2d(x, q(w, dt), padding=1) * osc + (b.view(1, -1, 1, 1) if with_bias else 0.0)
+    yv = ops.new_act(N, H - 1, W - 1, Cout, dt, DEV, zero=True)
+    pk = ops.pack_weight(dt, ops.OP_CONV, 0, w.to(DEV), Cin, Cout)
+    ops.conv_fwd(dt, ops.OP_CONV, to_view(x, dt), Cin, Cout, pk, yv, bias=None if b is None else b.to(DEV),
+                 oscale=torch.tensor([osc], device=DEV))
+    got = from_view(yv)
+    assert (got - want).abs().max().item() <= tol(dt, want.abs().max().item())
+
+
 def test_patchgan_head_kernel_matches_padconv():
     for dt in (DT_F32, DT_BF16):
         x = q(rnd((2, 512, 16, 16), 21), dt)

@@ -175,7 +175,7 @@ def test_full_size_properties_batch32():
     # temperature term (gradient-free, P16:587-595 / :607): the engine's value == the oracle's on the same fake_B
     want_t = float(O.temp_triplet_loss(fake[:4].cpu(), TB[:4].cpu(), B_tf[:4].cpu()))
     got_t = T.temperature_triplet_loss(fake[:4], TB[:4], B_tf[:4]).item()
-    assert abs(got_t - want_t) <= 1e-5 * abs(want_t)
+    assert abs(got_t - want_t) <= 1e-4 * abs(want_t) + 1e-6            # fp32 row norms, different summation order
     lg = 0.5 * out["loss_GAN_g"] + out["loss_triplet_patch"] + 0.01 * out["loss_FFT"] + 0.5 * out["loss_temp_g"]
     assert abs(float(lg) - float(out["loss_G"])) <= 1e-4 * abs(float(lg))
     for k, v in out.items():

@@ -345,6 +345,111 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// First-layer convolution (8 padded input channels x 16 taps: K = 128 = 8 k-substeps; G down1 3->64 and D block 1 6->64 at
+// 256 x 256): the generic kernel spends its life in prologue / epilogue here -- per 16 KB of output it re-reads 32 KB of weight
+// fragments and pays a workgroup launch. This variant is weights-stationary and persistent: a wave keeps its eight B fragments in
+// 32 VGPRs for the whole launch, a workgroup walks tiles  b, b + grid, ...; the halo of the tile after next is requested
+// BEFORE the current tile's stores are issued (vmcnt retires in order: a load issued behind stores would have to wait for them),
+// so nothing in the steady state ever waits for a store. Bound: the 266 MB output stream (HBM).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 4)
+tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* __restrict__ out,
+                   const float* __restrict__ bias, const float* __restrict__ oscale, int NB32, int nwork) {
+  constexpr int P = TFC_LDS_P, PS = 16, MT = 2;
+  constexpr int HB = TFC_MAX_HH * P * PS;                        // one halo buffer (4224 B)
+  constexpr int ROWP = 64 * 2 + 16;                              // staged output tile: 64 channels per pixel row + pad
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HB + 128 * ROWP];
+  unsigned char* stage = smem + 2 * HB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, r = lane & 31;
+  const TfcPlane& pd = d.plane[0];
+  const int G = gridDim.x;
+
+  uint4 bw[8];                                                   // this wave's 32 output channels x K = 128, for the whole launch
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bw[s] = wp[((size_t)s * NB32 + wn) * 64 + lane];
+  const int n = wn * 32 + r;
+  const float bv = (bias && n < d.Nout) ? bias[n] : 0.f;
+  const float osc = oscale ? *oscale : 1.f;
+
+  auto decode = [&](int w, int& img, int& a0, int& b0) {
+    int tile = tfc_xcd_remap(w, nwork);
+    const int txb = tile % d.tiles_x; tile /= d.tiles_x;
+    const int tyb = tile % d.tiles_y;
+    img = tile / d.tiles_y;
+    a0 = tyb * TFC_TILE_H; b0 = txb * TFC_TILE_W;
+  };
+  const int hpix = tid;                                          // one 16-byte halo unit (= one pixel) per thread
+  const int hy = hpix / pd.hw, hx = hpix - hy * pd.hw;
+  const bool hact = hpix < pd.hh * pd.hw;
+  const int hoff = (hy * P + hx) * PS;
+  auto halo_load = [&](int img, int a0, int b0) -> uint4 {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const int y = a0 + pd.dy0 + hy, x = b0 + pd.dx0 + hx;
+    if (hact && y >= 0 && y < d.IH && x >= 0 && x < d.IW)
+      v = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch);
+    return v;
+  };
+  const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * PS + h * PS;   // lane half h takes the odd tap of a k-substep
+  constexpr int MSTRIDE = 2 * P * PS;
+
+  int w = blockIdx.x;
+  int img, a0, b0, n_img = 0, n_a0 = 0, n_b0 = 0;
+  decode(w, img, a0, b0);
+  uint4 hv = halo_load(img, a0, b0);
+  if (hact) *reinterpret_cast<uint4*>(smem + hoff) = hv;
+  if (w + G < nwork) { decode(w + G, n_img, n_a0, n_b0); hv = halo_load(n_img, n_a0, n_b0); }
+  __syncthreads();
+
+  for (int k = 0;; ++k) {
+    const unsigned char* buf = smem + (k & 1) * HB + laneBase;
+    f32x16_t acc[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {                                // k-substep s = taps 2s (h = 0) and 2s + 1 (h = 1) of the 4 x 4 raster
+      const int off = ((s >> 1) * P + 2 * (s & 1)) * PS;
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const uint4 a = *reinterpret_cast<const uint4*>(buf + off + mi * MSTRIDE);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[s]), acc[mi], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+        const int ty = 2 * (wm * MT + mi) + (row & 1), tx = row >> 1;
+        *reinterpret_cast<bf16_t*>(stage + (ty * TFC_TILE_W + tx) * ROWP + n * 2) = f32_to_bf16(acc[mi][j] * osc + bv);
+      }
+    const bool has1 = (w + G) < nwork;
+    if (has1 && hact) *reinterpret_cast<uint4*>(smem + ((k + 1) & 1) * HB + hoff) = hv;
+    int nn_img = 0, nn_a0 = 0, nn_b0 = 0;
+    if (w + 2 * G < nwork) { decode(w + 2 * G, nn_img, nn_a0, nn_b0); hv = halo_load(nn_img, nn_a0, nn_b0); }   // before the stores below
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int pix = idx >> 3, u = idx & 7;
+      const int a = a0 + (pix >> 4), b = b0 + (pix & 15);
+      if (a < d.GH && b < d.GW && u * 8 < d.Nout) {
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * ROWP + u * 16);
+        store_stream16(out + ((size_t)(img * d.OH + a + d.OOY) * d.OW + b + d.OOX) * d.out_pitch + u * 8, v);
+      }
+    }
+    if (!has1) break;
+    __syncthreads();                                             // the staged tile is free again
+    w += G; img = n_img; a0 = n_a0; b0 = n_b0; n_img = nn_img; n_a0 = nn_a0; n_b0 = nn_b0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight-gradient GEMM for 2 x 2-tap planes (bf16): the sub-pixel phases of the transposed convolution and phase (0,0) of the
 // upsample-conv. With only four taps the generic kernel gives each wave ONE tap (3 transposing LDS reads per MFMA); here a
 // workgroup owns 64 n x 64 c and wave (nh, ch) owns the 32 n x 32 c quadrant for ALL four taps: the B fragments of halo rows
@@ -996,6 +1101,25 @@ template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
                                  float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   const int nb = tfc_nb32(d.Nout);
+  if constexpr (sizeof(T) == 2) {
+    // first-layer shape (8 padded input channels, 4 x 4 raster taps, <= 64 output channels, bias / scale epilogue only)
+    if (g_tfc_force_cfg < 0 && d.Cin_pad == 8 && d.nplanes == 1 && d.ph_n <= 1 && d.SS == 1 && d.OS == 1 && plane_pattern(d.plane[0]) == 1 &&
+        d.Nout <= 64 && d.Nout % 8 == 0 && (flags & ~TFC_EP_BIAS) == 0) {
+      static int grid_cap = 0;
+      if (!grid_cap) {
+        int occ = 0, dev = 0, ncu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_conv_c8_kernel, 256, 0);
+        if (e != hipSuccess) return e;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        grid_cap = (occ < 1 ? 1 : occ) * ncu;
+      }
+      const int nwork = d.nimg * d.tiles_y * d.tiles_x;
+      hipLaunchKernelGGL(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
+                         (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, tfc_nb32_padded(d.Nout), nwork);
+      return hipGetLastError();
+    }
+  }
   if (g_tfc_force_cfg == 3 && nb >= 4) return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if (g_tfc_force_cfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if ((g_tfc_force_cfg == 0 || g_tfc_force_cfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
