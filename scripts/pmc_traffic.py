@@ -35,6 +35,8 @@ def main():
         wk = write[k][0] / max(write[k][1], 1) if k in write else 0.0
         res[k] = {"launches_profiled": n, "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk,
                   "hbm_bytes_per_launch_corrected": (2.0 * fk + wk) * 1024.0}
+    if not res:
+        sys.exit(f"no counter data under {d}: {dst} left untouched")
     json.dump(res, open(dst, "w"), indent=1)
     for k, v in list(res.items())[:12]:
         print(f"{k:34s} {v['launches_profiled']:5d} launches  {v['hbm_bytes_per_launch_corrected'] / 1e6:9.1f} MB/launch")
