@@ -38,6 +38,7 @@ extern "C" {
 #define TFC_EP_STATS 2      /* stats[N][Cout][2] += (sum, sum of squares) of the result: nn.InstanceNorm2d statistics, P16:107 */
 #define TFC_EP_ACCUM 4      /* result += existing output (skip-connection gradient accumulation, torch.cat backward P16:133)  */
 #define TFC_EP_TANH_NCHW 8  /* nn.Tanh (P16:157) and store fp32 NCHW to `out_nchw`                                            */
+#define TFC_EP_LEAKY 16     /* nn.LeakyReLU(0.2) of Discriminator1 (P16:190) applied to the result before it is stored          */
 
 const char* tfc_last_error(void);
 int tfc_abi_version(void);

@@ -150,10 +150,12 @@ def test_first_layer_weights_stationary_kernel(N, H, W, Cin, Cout, with_bias):
     b = rnd((Cout,), 7, 0.5) if with_bias else None
     osc = 0.37
     want = F.conv2d(x, q(w, dt), padding=1) * osc + (b.view(1, -1, 1, 1) if with_bias else 0.0)
+    if with_bias:                                                            # discriminator block 1: + LeakyReLU(0.2) in the epilogue
+        want = F.leaky_relu(want, 0.2)
     yv = ops.new_act(N, H - 1, W - 1, Cout, dt, DEV, zero=True)
     pk = ops.pack_weight(dt, ops.OP_CONV, 0, w.to(DEV), Cin, Cout)
     ops.conv_fwd(dt, ops.OP_CONV, to_view(x, dt), Cin, Cout, pk, yv, bias=None if b is None else b.to(DEV),
-                 oscale=torch.tensor([osc], device=DEV))
+                 oscale=torch.tensor([osc], device=DEV), flags=ops.EP_LEAKY if with_bias else 0)
     got = from_view(yv)
     assert (got - want).abs().max().item() <= tol(dt, want.abs().max().item())
 

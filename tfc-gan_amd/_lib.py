@@ -18,7 +18,7 @@ PUBLIC_HEADER = os.path.join(_ROOT, "include", "tfc_gan.h")
 
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_PADCONV, OP_CONVT, OP_UPCONV = 0, 1, 2, 3
-EP_BIAS, EP_STATS, EP_ACCUM, EP_TANH_NCHW = 1, 2, 4, 8
+EP_BIAS, EP_STATS, EP_ACCUM, EP_TANH_NCHW, EP_LEAKY = 1, 2, 4, 8, 16
 
 _lock = threading.Lock()
 _lib = None

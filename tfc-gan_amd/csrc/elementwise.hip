@@ -109,7 +109,9 @@ tfc_act_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __re
 
 // Stride-2 BlurPool forward, separable and blocked: a thread produces a 2x2 block of outputs from its 6x6 input window --
 // 36 loads / activations per 4 outputs instead of 64 -- horizontal [1,3,3,1]/8 pass per input row, then the vertical pass.
-template <typename T>
+// ACT = false: no normalisation and identity activation (discriminator blocks, whose LeakyReLU already ran in the conv epilogue):
+// a pure anti-aliased down-sampling, without the 2.25x-redundant activation arithmetic.
+template <typename T, bool ACT>
 __global__ void __launch_bounds__(256)
 tfc_act_pool2_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __restrict__ stats, T* __restrict__ out) {
   constexpr int UE = ElemTraits<T>::UE;
@@ -158,8 +160,11 @@ tfc_act_pool2_fwd_kernel(const ActParams p, const T* __restrict__ x, const float
         unpack16<T>(*reinterpret_cast<const uint4*>(row + (size_t)cx[j] * p.x_pitch), v);
 #pragma unroll
         for (int e = 0; e < UE; ++e) {
-          float t = p.norm ? (v[e] - mean[e]) * rstd[e] : v[e];
-          t = t > 0.f ? t : t * p.slope;
+          float t = v[e];
+          if (ACT) {
+            t = p.norm ? (t - mean[e]) * rstd[e] : t;
+            t = t > 0.f ? t : t * p.slope;
+          }
           if (j < 4) h0[e] += blur_w(j) * t;
           if (j >= 2) h1[e] += blur_w(j - 2) * t;
         }
@@ -1080,7 +1085,10 @@ template <typename T>
 static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st) {
   if (p.pool == 2 && !stats_out) {
     const dim3 g2 = act_grid(((p.Ho + 1) / 2) * ((p.Wo + 1) / 2), p.C, ElemTraits<T>::UE, p.N);
-    hipLaunchKernelGGL((tfc_act_pool2_fwd_kernel<T>), g2, dim3(256), 0, st, p, (const T*)x, stats, (T*)out);
+    if (!p.norm && p.slope == 1.f)
+      hipLaunchKernelGGL((tfc_act_pool2_fwd_kernel<T, false>), g2, dim3(256), 0, st, p, (const T*)x, stats, (T*)out);
+    else
+      hipLaunchKernelGGL((tfc_act_pool2_fwd_kernel<T, true>), g2, dim3(256), 0, st, p, (const T*)x, stats, (T*)out);
     return hipGetLastError();
   }
   if (p.pool == 1 && !p.norm && p.slope == 1.f && !p.drop_thresh24 &&

@@ -279,6 +279,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         const int a = a0 + ty, b = b0 + tx;
         const bool ok = nok && a < d.GH && b < d.GW;
         float v = acc[mi][nt][j] * osc + bv;
+        if (flags & TFC_EP_LEAKY) v = fmaxf(v, 0.2f * v);
         if (STAGED && !(flags & TFC_EP_TANH_NCHW)) {
           if (ok) { s1 += v; s2 += v * v; }
           *reinterpret_cast<bf16_t*>(smem + (ty * TFC_TILE_W + tx) * ROWP + ((wn * NT + nt) * 32 + r) * 2) = f32_to_bf16(v);
@@ -354,7 +355,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4)
 tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* __restrict__ out,
-                   const float* __restrict__ bias, const float* __restrict__ oscale, int NB32, int nwork) {
+                   const float* __restrict__ bias, const float* __restrict__ oscale, int leaky, int NB32, int nwork) {
   constexpr int P = TFC_LDS_P, PS = 16, MT = 2;
   constexpr int HB = TFC_MAX_HH * P * PS;                        // one halo buffer (4224 B)
   constexpr int ROWP = 64 * 2 + 16;                              // staged output tile: 64 channels per pixel row + pad
@@ -426,7 +427,9 @@ tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4
       for (int j = 0; j < 16; ++j) {
         const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
         const int ty = 2 * (wm * MT + mi) + (row & 1), tx = row >> 1;
-        *reinterpret_cast<bf16_t*>(stage + (ty * TFC_TILE_W + tx) * ROWP + n * 2) = f32_to_bf16(acc[mi][j] * osc + bv);
+        float v = acc[mi][j] * osc + bv;
+        if (leaky) v = fmaxf(v, 0.2f * v);
+        *reinterpret_cast<bf16_t*>(stage + (ty * TFC_TILE_W + tx) * ROWP + n * 2) = f32_to_bf16(v);
       }
     const bool has1 = (w + G) < nwork;
     if (has1 && hact) *reinterpret_cast<uint4*>(smem + ((k + 1) & 1) * HB + hoff) = hv;
@@ -1104,7 +1107,7 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
   if constexpr (sizeof(T) == 2) {
     // first-layer shape (8 padded input channels, 4 x 4 raster taps, <= 64 output channels, bias / scale epilogue only)
     if (g_tfc_force_cfg < 0 && d.Cin_pad == 8 && d.nplanes == 1 && d.ph_n <= 1 && d.SS == 1 && d.OS == 1 && plane_pattern(d.plane[0]) == 1 &&
-        d.Nout <= 64 && d.Nout % 8 == 0 && (flags & ~TFC_EP_BIAS) == 0) {
+        d.Nout <= 64 && d.Nout % 8 == 0 && (flags & ~(TFC_EP_BIAS | TFC_EP_LEAKY)) == 0) {
       static int grid_cap = 0;
       if (!grid_cap) {
         int occ = 0, dev = 0, ncu = 0;
@@ -1116,7 +1119,7 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
       }
       const int nwork = d.nimg * d.tiles_y * d.tiles_x;
       hipLaunchKernelGGL(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
-                         (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, tfc_nb32_padded(d.Nout), nwork);
+                         (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork);
       return hipGetLastError();
     }
   }

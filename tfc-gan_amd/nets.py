@@ -288,9 +288,12 @@ class DiscriminatorCore:
             sigma2 = sig[bi]
             h = cur.H
             raw = new_act(N, h - 1, h - 1, cout, dt, dev)
-            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:])
+            # SN-conv + bias + LeakyReLU(0.2) in one kernel (P16:188-190): `raw` holds the ACTIVATED tensor; the backward's slope test
+            # (y > 0) is the same on y = LeakyReLU(z) as on z, so act_bwd below keeps slope = 0.2 on this tensor
+            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:],
+                         flags=ops.EP_LEAKY)
             out = new_act(N, pooled(h - 1), pooled(h - 1), cout, dt, dev)
-            ops.act_fwd(dt, raw, out, stats=None, slope=0.2, pool=2)
+            ops.act_fwd(dt, raw, out, stats=None, slope=1.0, pool=2)
             ctx.ins.append(cur)
             ctx.raw.append(raw)
             ctx.sn.append((usn[bi], vsn[bi], sigma2) if save else None)

@@ -9,7 +9,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (DT_BF16, DT_F32, EP_ACCUM, EP_BIAS, EP_STATS, EP_TANH_NCHW, OP_CONV, OP_CONVT, OP_PADCONV, OP_UPCONV, check)
+from ._lib import (DT_BF16, DT_F32, EP_ACCUM, EP_BIAS, EP_LEAKY, EP_STATS, EP_TANH_NCHW, OP_CONV, OP_CONVT, OP_PADCONV, OP_UPCONV, check)
 
 
 def lib():
