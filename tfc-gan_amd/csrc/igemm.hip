@@ -931,6 +931,138 @@ hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Transposed-convolution weight gradient, all four sub-pixel phases in ONE launch (bf16).
+//   dW[ci][co][ky][kx] = sum_{a,b} x[a][b][ci] * dy[2a-1+ky][2b-1+kx][co]
+// Phase (py,px) of the output grid owns the taps ky = 1-py+2jy, kx = 1-px+2jx and reads x at (a+py-jy, b+px-jx). The per-phase
+// launches re-read the input halo four times and moved 118 FLOP per byte; here a workgroup owns 32 n (= co) x 32 c (= ci), stages
+// the (8+2) x (16+2) halo of x ONCE plus the four parity sub-grids of the 16 x 32 patch of dy, and wave w = phase (py,px) runs its
+// 2 x 2 taps with the sliding two-row window of tfc_wgrad22_kernel (1 A + 2 new B fragments per 4 MFMAs): 380 FLOP per byte, one
+// launch and one slab set per layer instead of four. Split-K partials go to slabs (tfc_wgrad_reduce_kernel kind 2).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 3)
+tfc_wgradT_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int Cin_pad, const bf16_t* __restrict__ dy, int dy_pitch,
+                  int Nn_pad, int nimg, float4* slab, int nbw, int ncb, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROWB = 64;                                       // 32 channels x 2 bytes per LDS pixel row
+  constexpr int HH = TFC_TILE_H + 2, HW = TFC_TILE_W + 2;
+  constexpr int DO_BYTES = 4 * 128 * ROWB;                       // [phase][px][32 n]
+  constexpr int HALO_BYTES = HH * HW * ROWB;
+  constexpr int NDO = DO_BYTES / 16 / 256, NHA = (HH * HW * 4 + 255) / 256;   // 8 and 3 units per thread
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int py = wave >> 1, px = wave & 1;
+  const int OH = 2 * IH, OW = 2 * IW;
+  const int tiles_y = (IH + TFC_TILE_H - 1) / TFC_TILE_H, tiles_x = (IW + TFC_TILE_W - 1) / TFC_TILE_W;
+  const int ntiles = nimg * tiles_y * tiles_x;
+
+  const int bid = tfc_xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = bid % (nbw * ncb);
+  const int sp = bid / (nbw * ncb);
+  const int cb = pair % ncb, nb = pair / ncb;
+
+  f32x16_t acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
+
+  uint4 vdo[NDO], vha[NHA];
+  auto tile_load = [&](int tl) {
+    int t = tl;
+    const int txb = t % tiles_x; t /= tiles_x;
+    const int tyb = t % tiles_y;
+    const int img = t / tiles_y;
+    const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) {
+      const int idx = tid + i * 256;                             // ((phase * 128) + pixel) * 4 + g
+      const int g = idx & 3, pxl = (idx >> 2) & 127, ph = idx >> 9;
+      const int a = a0 + (pxl >> 4), b = b0 + (pxl & 15);
+      const int n0 = nb * 32 + g * 8;
+      vdo[i] = make_uint4(0, 0, 0, 0);
+      if (a < IH && b < IW && n0 < Nn_pad)
+        vdo[i] = *reinterpret_cast<const uint4*>(dy + ((size_t)(img * OH + 2 * a + (ph >> 1)) * OW + 2 * b + (ph & 1)) * dy_pitch + n0);
+    }
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;                             // pixel * 4 + g
+      vha[i] = make_uint4(0, 0, 0, 0);
+      if (idx < HH * HW * 4) {
+        const int g = idx & 3, pix = idx >> 2;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int y = a0 - 1 + hy, xx = b0 - 1 + hx;
+        const int c0 = cb * 32 + g * 8;
+        if (y >= 0 && y < IH && xx >= 0 && xx < IW && c0 < Cin_pad)
+          vha[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(img * IH + y) * IW + xx) * x_pitch + c0);
+      }
+    }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) *reinterpret_cast<uint4*>(smem + (tid + i * 256) * 16) = vdo[i];
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < HH * HW * 4) *reinterpret_cast<uint4*>(smem + DO_BYTES + idx * 16) = vha[i];
+    }
+  };
+
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trLane = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;
+  auto tr16 = [&](const unsigned char* p0) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + 4 * ROWB));
+    uint4 r;
+    r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  };
+  // accumulator g = dyg * 2 + dxg : halo row kt + py + dyg, column shift px + dxg  (filter tap jy = 1 - dyg, jx = 1 - dxg)
+  auto compute = [&]() {
+    const unsigned char* acol = smem + wave * 128 * ROWB + trLane;
+    const unsigned char* hcol = smem + DO_BYTES + (py * HW + px) * ROWB + trLane;
+    constexpr int rowb = HW * ROWB;
+    uint4 b0[2], b1[2];
+    b0[0] = tr16(hcol);
+    b0[1] = tr16(hcol + ROWB);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      b1[0] = tr16(hcol + (kt + 1) * rowb);
+      b1[1] = tr16(hcol + (kt + 1) * rowb + ROWB);
+      const bf16x8_t av = __builtin_bit_cast(bf16x8_t, tr16(acol + kt * 16 * ROWB));
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b0[0]), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b0[1]), acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b1[0]), acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b1[1]), acc[3], 0, 0, 0);
+      b0[0] = b1[0]; b0[1] = b1[1];
+    }
+  };
+
+  int tl = sp;
+  if (tl < ntiles) { tile_load(tl); tile_store(); }
+  __syncthreads();
+  for (; tl < ntiles; tl += nsplit) {
+    const bool more = (tl + nsplit) < ntiles;
+    if (more) tile_load(tl + nsplit);                            // next tile -> registers while this one is multiplied
+    compute();
+    __syncthreads();                                             // single LDS image: everyone is done reading it
+    if (more) tile_store();
+    __syncthreads();
+  }
+
+  float4* ps = slab + ((size_t)bid * 4 + wave) * (4 * 4 * 64) + lane;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      ps[(a * 4 + q4) * 64] = make_float4(acc[a][4 * q4], acc[a][4 * q4 + 1], acc[a][4 * q4 + 2], acc[a][4 * q4 + 3]);
+}
+
 // Split-K reduction of the weight-gradient slabs. fp32 atomics run at ~1.3 TB/s on this chip (they execute at the memory side) and a
 // one-round wgrad launch flushes the WHOLE chip's accumulator state (~67 MB): ~50 us of a ~130 us kernel. Instead every workgroup
 // stores its accumulators, in register order, with plain 16-byte stores (~6 TB/s): slab[workgroup = sp*npairs + pair][wave][tile a][q][lane]
@@ -938,6 +1070,7 @@ hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int 
 // waves take every fourth split, LDS combine) and adds the result to acc[slot][n][c] -- one thread per element, no atomics.
 //   kind 0 (tfc_wgrad_kernel):   wave = tap % 4, tile a = (tap / 4) * 2 + ni;     n = nb*64 + ni*32 + row, c = cb*32 + (lane & 31)
 //   kind 1 (tfc_wgrad22_kernel): wave = ch*2 + nh, tile a = tap_dy*2 + tap_dx;     n = nb*64 + nh*32 + row, c = (cb*2+ch)*32 + (lane & 31)
+//   kind 2 (tfc_wgradT_kernel):  wave = phase, tile a = dyg*2 + dxg -> filter tap (1-py+2(1-dyg), 1-px+2(1-dxg)); n = nb*32 + row
 //   row of register j = 4q+e in lane l:  e + 8q + 4*(l >> 5)
 __global__ void __launch_bounds__(256)
 tfc_wgrad_reduce_kernel(const float4* __restrict__ slab, float* acc, const TfcPlane pd, int kind, int T, int nsplit, int npairs, int ncbx,
@@ -964,7 +1097,12 @@ tfc_wgrad_reduce_kernel(const float4* __restrict__ slab, float* acc, const TfcPl
   for (int i = 1; i < 4; ++i) { const float4 v = part[i][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   const int cbx = pair % ncbx, nb = pair / ncbx;
   int mask = 0, n0, c;
-  if (kind == 0) {
+  if (kind == 2) {                                               // tfc_wgradT_kernel: wave = phase (py,px), a = dyg*2 + dxg, 32 n per workgroup
+    const int jy = 1 - (a >> 1), jx = 1 - (a & 1);
+    mask = 1 << ((1 - (wave >> 1) + 2 * jy) * 4 + (1 - (wave & 1) + 2 * jx));
+    n0 = nb * 32;
+    c = cbx * 32 + (lane & 31);
+  } else if (kind == 0) {
     const int tap = (a >> 1) * 4 + wave;
     if (tap < pd.ntaps) mask = pd.tap_mask[tap];
     n0 = nb * 64 + (a & 1) * 32;
@@ -1188,6 +1326,26 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
     hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * (tw * 2) * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 0, tw * 2, nsplit,
                        nbw * ncb, ncb, Nn_real, Cw_real);
   return hipGetLastError();
+}
+// transposed convolution, bf16: all four phases in one launch (slab: 768 workgroups x 64 KiB at most); false = not applicable
+bool tfc_launch_wgrad_convT_fused(const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
+                                  int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err) {
+  if (g_tfc_force_cfg == 2) return false;                         // tests: keep the per-phase kernels reachable
+  const int Nn_pad = (Cout + 7) / 8 * 8;
+  const int nbw = (Nn_pad + 31) / 32, ncb = (Cin_pad + 31) / 32;
+  const int ntiles = N * ((IH + TFC_TILE_H - 1) / TFC_TILE_H) * ((IW + TFC_TILE_W - 1) / TFC_TILE_W);
+  int nsplit = 768 / (nbw * ncb);                                 // 3 workgroups per CU (44 KB LDS, <= 168 VGPRs)
+  if (nsplit > ntiles) nsplit = ntiles;
+  if (nsplit < 1) nsplit = 1;
+  if ((size_t)nbw * ncb * nsplit * 4 * 16 * 64 * 16 > ((size_t)512 * 4 * 8 * 4 * 64 * 16)) return false;   // slab budget of api.hip
+  const int lds = 4 * 128 * 64 + (TFC_TILE_H + 2) * (TFC_TILE_W + 2) * 64;
+  hipLaunchKernelGGL(tfc_wgradT_kernel, dim3(nbw * ncb * nsplit), dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad,
+                     (const bf16_t*)dy, dy_pitch, Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
+  TfcPlane none{};
+  hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * 4 * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 2, 4, nsplit,
+                     nbw * ncb, ncb, Cout, Cin);
+  *err = hipGetLastError();
+  return true;
 }
 // slab: >= TFC_WGRAD_SLAB_BYTES of scratch for the split-K partials (bf16 path); nullptr = flush with fp32 atomics (fp32 parity mode)
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad,
