@@ -27,8 +27,8 @@ size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
-bool tfc_launch_wgrad_convT_fused(const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
-                                  int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err);
+bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
+                                   int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err);
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
 hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st);
 hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st);
@@ -461,12 +461,13 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
   {
     ProfScope prof(1, conv_flop(op, N, H, W, Cin, Cout), st);
     bool fused = false;
-    if (op == TFC_OP_CONVT && dt == TFC_DT_BF16) {               // all four sub-pixel phases in one launch
+    if ((op == TFC_OP_CONVT || op == TFC_OP_UPCONV) && dt == TFC_DT_BF16) {   // all four sub-pixel phases in one launch
       TfcGather d0;
       if (int e = build_desc(op, 2, 0, N, H, W, Cin, Cout, x_pitch, dy_pitch, &d0, &wm)) return e;   // wm: the weight layout map
       hipError_t herr = hipSuccess;
-      fused = tfc_launch_wgrad_convT_fused(x, N, H, W, x_pitch, pad8(Cin), dy, dy_pitch, Cout, Cin, (float*)((char*)ws + kWgradSlabBytes), ws, st, &herr);
-      if (fused) CHECK_HIP(herr, "tfc_conv_wgrad (fused transposed conv)");
+      fused = tfc_launch_wgrad_phases_fused(op == TFC_OP_UPCONV, x, N, H, W, x_pitch, pad8(Cin), dy, dy_pitch, Cout, Cin,
+                                            (float*)((char*)ws + kWgradSlabBytes), ws, st, &herr);
+      if (fused) CHECK_HIP(herr, "tfc_conv_wgrad (phase-fused)");
     }
     for (int ph = 0; ph < num_phases(op, 2) && !fused; ++ph) {
       TfcGather d;

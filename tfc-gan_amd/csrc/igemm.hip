@@ -19,6 +19,7 @@
 //   * epilogue fuses bias, InstanceNorm statistics (wave-shuffle + fp32 atomics), skip-gradient
 //     accumulation, and tanh + NCHW store for the generator head.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "pack_math.h"
 
@@ -940,15 +941,20 @@ hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int 
 // 2 x 2 taps with the sliding two-row window of tfc_wgrad22_kernel (1 A + 2 new B fragments per 4 MFMAs): 380 FLOP per byte, one
 // launch and one slab set per layer instead of four. Split-K partials go to slabs (tfc_wgrad_reduce_kernel kind 2).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 3)
+// UP = true: the same structure for the upsample(2x nearest) + ZeroPad(1,0,1,0) + conv head (generator `final`, P16:150-157):
+//   dW[co][ci][ky][kx] = sum dy[2a+py][2b+px][co] * x[a + off(py,ky)][b + off(px,kx)][ci],  off(0,.) = {-1,-1,0,0}, off(1,.) = {-1,0,0,1}
+// -- phase (py,px) has (2+py) x (2+px) distinct source offsets (collapsed taps; the reduce kernel adds each to all the filter taps it
+// stands for), read from the same 10 x 18 halo.
+template <bool UP>
+__global__ void __launch_bounds__(256, UP ? 2 : 3)
 tfc_wgradT_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int Cin_pad, const bf16_t* __restrict__ dy, int dy_pitch,
                   int Nn_pad, int nimg, float4* slab, int nbw, int ncb, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWB = 64;                                       // 32 channels x 2 bytes per LDS pixel row
   constexpr int HH = TFC_TILE_H + 2, HW = TFC_TILE_W + 2;
   constexpr int DO_BYTES = 4 * 128 * ROWB;                       // [phase][px][32 n]
-  constexpr int HALO_BYTES = HH * HW * ROWB;
   constexpr int NDO = DO_BYTES / 16 / 256, NHA = (HH * HW * 4 + 255) / 256;   // 8 and 3 units per thread
+  constexpr int NCM = UP ? 3 : 2, NA = NCM * NCM;                // accumulator tiles per wave: (row offset, column offset)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -962,9 +968,9 @@ tfc_wgradT_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int
   const int sp = bid / (nbw * ncb);
   const int cb = pair % ncb, nb = pair / ncb;
 
-  f32x16_t acc[4];
+  f32x16_t acc[NA];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
 
@@ -1022,42 +1028,55 @@ tfc_wgradT_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int
     r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
     return r;
   };
-  // accumulator g = dyg * 2 + dxg : halo row kt + py + dyg, column shift px + dxg  (filter tap jy = 1 - dyg, jx = 1 - dxg)
-  auto compute = [&]() {
+  // Accumulator (r, c): halo row kt + rb + r, column shift cs + c, with a sliding window of NR rows (wave-uniform NR, NC in {2, 3}).
+  //   transposed conv: rb = py, cs = px, 2 x 2 (filter tap jy = 1 - r, jx = 1 - c);  upsample conv: rb = cs = 0, (2+py) x (2+px)
+  const int rb = UP ? 0 : py, cs = UP ? 0 : px;
+  constexpr int rowb = HW * ROWB;
+  auto compute_v = [&](auto nr_tag, auto nc_tag) {
+    constexpr int NR = decltype(nr_tag)::value, NC = decltype(nc_tag)::value;
     const unsigned char* acol = smem + wave * 128 * ROWB + trLane;
-    const unsigned char* hcol = smem + DO_BYTES + (py * HW + px) * ROWB + trLane;
-    constexpr int rowb = HW * ROWB;
-    uint4 b0[2], b1[2];
-    b0[0] = tr16(hcol);
-    b0[1] = tr16(hcol + ROWB);
+    const unsigned char* hcol = smem + DO_BYTES + (rb * HW + cs) * ROWB + trLane;
+    uint4 rw[NR][NC];
+#pragma unroll
+    for (int r = 0; r < NR - 1; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) rw[r][c] = tr16(hcol + r * rowb + c * ROWB);
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
-      b1[0] = tr16(hcol + (kt + 1) * rowb);
-      b1[1] = tr16(hcol + (kt + 1) * rowb + ROWB);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) rw[NR - 1][c] = tr16(hcol + (kt + NR - 1) * rowb + c * ROWB);
       const bf16x8_t av = __builtin_bit_cast(bf16x8_t, tr16(acol + kt * 16 * ROWB));
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b0[0]), acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b0[1]), acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b1[0]), acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, b1[1]), acc[3], 0, 0, 0);
-      b0[0] = b1[0]; b0[1] = b1[1];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[r * NCM + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, rw[r][c]), acc[r * NCM + c], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < NR - 1; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) rw[r][c] = rw[r + 1][c];
     }
   };
+  // upsample conv: every wave runs the full 3 x 3 offset grid; the offsets a phase does not have (row 2 for py = 0, column 2 for
+  // px = 0) only fill accumulators that the reduce kernel ignores -- cheaper than four differently shaped code paths
+  auto compute = [&]() { compute_v(std::integral_constant<int, NCM>{}, std::integral_constant<int, NCM>{}); };
 
   int tl = sp;
   if (tl < ntiles) { tile_load(tl); tile_store(); }
   __syncthreads();
   for (; tl < ntiles; tl += nsplit) {
     const bool more = (tl + nsplit) < ntiles;
-    if (more) tile_load(tl + nsplit);                            // next tile -> registers while this one is multiplied
+    if (!UP && more) tile_load(tl + nsplit);                     // next tile -> registers while this one is multiplied
     compute();
     __syncthreads();                                             // single LDS image: everyone is done reading it
+    if (UP && more) tile_load(tl + nsplit);                      // nine accumulator tiles leave no room for the staging registers: load late
     if (more) tile_store();
     __syncthreads();
   }
 
-  float4* ps = slab + ((size_t)bid * 4 + wave) * (4 * 4 * 64) + lane;
+  float4* ps = slab + ((size_t)bid * 4 + wave) * (NA * 4 * 64) + lane;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4)
       ps[(a * 4 + q4) * 64] = make_float4(acc[a][4 * q4], acc[a][4 * q4 + 1], acc[a][4 * q4 + 2], acc[a][4 * q4 + 3]);
@@ -1074,14 +1093,14 @@ tfc_wgradT_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int
 //   row of register j = 4q+e in lane l:  e + 8q + 4*(l >> 5)
 __global__ void __launch_bounds__(256)
 tfc_wgrad_reduce_kernel(const float4* __restrict__ slab, float* acc, const TfcPlane pd, int kind, int T, int nsplit, int npairs, int ncbx,
-                        int Nn_real, int Cw_real) {
+                        int Nn_real, int Cw_real, int wave_only) {
   __shared__ float4 part[4][64];
   const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-  int rowid = blockIdx.x;                                        // ((pair * 4 + wave) * T + a) * 4 + q
+  int rowid = blockIdx.x;                                        // ((pair * 4 + wave) * T + a) * 4 + q   (wave_only >= 0: (pair * T + a) * 4 + q)
   const int q = rowid & 3; rowid >>= 2;
   const int a = rowid % T; rowid /= T;
-  const int wave = rowid & 3;
-  const int pair = rowid >> 2;
+  const int wave = wave_only >= 0 ? wave_only : (rowid & 3);
+  const int pair = wave_only >= 0 ? rowid : (rowid >> 2);
   const size_t blk_units = (size_t)4 * T * 4 * 64;
   const float4* p0 = slab + ((size_t)pair * 4 + wave) * (T * 4 * 64) + (a * 4 + q) * 64 + lane;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1097,7 +1116,18 @@ tfc_wgrad_reduce_kernel(const float4* __restrict__ slab, float* acc, const TfcPl
   for (int i = 1; i < 4; ++i) { const float4 v = part[i][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   const int cbx = pair % ncbx, nb = pair / ncbx;
   int mask = 0, n0, c;
-  if (kind == 2) {                                               // tfc_wgradT_kernel: wave = phase (py,px), a = dyg*2 + dxg, 32 n per workgroup
+  if (kind == 3) {                                               // tfc_wgradT_kernel<true>: wave = phase, a = ir*3 + ic (collapsed taps of the upsample conv)
+    const int wpy = wave >> 1, wpx = wave & 1, ir = a / 3, ic = a % 3;
+    if (ir < 2 + wpy && ic < 2 + wpx)
+      for (int ky = 0; ky < 4; ++ky)
+        for (int kx = 0; kx < 4; ++kx) {
+          const int sy = wpy ? (ky == 0 ? 0 : (ky == 3 ? 2 : 1)) : (ky >> 1);   // source row offset + 1 of filter row ky in this phase
+          const int sx = wpx ? (kx == 0 ? 0 : (kx == 3 ? 2 : 1)) : (kx >> 1);
+          if (sy == ir && sx == ic) mask |= 1 << (ky * 4 + kx);
+        }
+    n0 = nb * 32;
+    c = cbx * 32 + (lane & 31);
+  } else if (kind == 2) {                                        // tfc_wgradT_kernel: wave = phase (py,px), a = dyg*2 + dxg, 32 n per workgroup
     const int jy = 1 - (a >> 1), jx = 1 - (a & 1);
     mask = 1 << ((1 - (wave >> 1) + 2 * jy) * 4 + (1 - (wave & 1) + 2 * jx));
     n0 = nb * 32;
@@ -1309,7 +1339,7 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
                          Nn_pad, Nn_real, Cw_real, nbw, ncb2, ns);
       if (slab)
         hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb2 * 4 * 4 * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 1, 4, ns, nbw * ncb2,
-                           ncb2, Nn_real, Cw_real);
+                           ncb2, Nn_real, Cw_real, -1);
       return hipGetLastError();
     }
   }
@@ -1324,26 +1354,39 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
 #undef TFC_WG
   if (slab)
     hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * (tw * 2) * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 0, tw * 2, nsplit,
-                       nbw * ncb, ncb, Nn_real, Cw_real);
+                       nbw * ncb, ncb, Nn_real, Cw_real, -1);
   return hipGetLastError();
 }
-// transposed convolution, bf16: all four phases in one launch (slab: 768 workgroups x 64 KiB at most); false = not applicable
-bool tfc_launch_wgrad_convT_fused(const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
-                                  int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err) {
+// transposed convolution / upsample conv, bf16: all four phases in one launch; false = not applicable (caller falls back to per-phase launches)
+bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
+                                   int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err) {
   if (g_tfc_force_cfg == 2) return false;                         // tests: keep the per-phase kernels reachable
   const int Nn_pad = (Cout + 7) / 8 * 8;
   const int nbw = (Nn_pad + 31) / 32, ncb = (Cin_pad + 31) / 32;
   const int ntiles = N * ((IH + TFC_TILE_H - 1) / TFC_TILE_H) * ((IW + TFC_TILE_W - 1) / TFC_TILE_W);
-  int nsplit = 768 / (nbw * ncb);                                 // 3 workgroups per CU (44 KB LDS, <= 168 VGPRs)
+  const int T = up ? 9 : 4;                                       // accumulator tiles per wave
+  const size_t blk_bytes = (size_t)4 * T * 4 * 64 * 16;           // slab bytes per workgroup
+  int nsplit = (up ? 512 : 768) / (nbw * ncb);                    // 2 / 3 workgroups per CU (44 KB LDS; <= 256 / 168 VGPRs)
+  const size_t budget = (size_t)512 * 4 * 8 * 4 * 64 * 16;        // slab bytes api.hip reserves
+  if ((size_t)nbw * ncb * blk_bytes > budget) return false;
+  if ((size_t)nbw * ncb * nsplit * blk_bytes > budget) nsplit = (int)(budget / ((size_t)nbw * ncb * blk_bytes));
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
-  if ((size_t)nbw * ncb * nsplit * 4 * 16 * 64 * 16 > ((size_t)512 * 4 * 8 * 4 * 64 * 16)) return false;   // slab budget of api.hip
   const int lds = 4 * 128 * 64 + (TFC_TILE_H + 2) * (TFC_TILE_W + 2) * 64;
-  hipLaunchKernelGGL(tfc_wgradT_kernel, dim3(nbw * ncb * nsplit), dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad,
-                     (const bf16_t*)dy, dy_pitch, Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
+  const dim3 grid(nbw * ncb * nsplit);
   TfcPlane none{};
-  hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * 4 * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 2, 4, nsplit,
-                     nbw * ncb, ncb, Cout, Cin);
+  if (up) {
+    hipLaunchKernelGGL(tfc_wgradT_kernel<true>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
+                       Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
+    for (int wv = 0; wv < 4; ++wv)                                // the phases overlap on the filter taps: one reduce pass per phase, in order
+      hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 3, T, nsplit,
+                         nbw * ncb, ncb, Cout, Cin, wv);
+  } else {
+    hipLaunchKernelGGL(tfc_wgradT_kernel<false>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
+                       Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
+    hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 2, T, nsplit,
+                       nbw * ncb, ncb, Cout, Cin, -1);
+  }
   *err = hipGetLastError();
   return true;
 }
