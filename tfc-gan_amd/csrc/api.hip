@@ -197,9 +197,11 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
       }
       case TFC_OP_UPCONV: {
         // out[2a+p] reads source row a + off(p,k): the 4 filter rows hit only 2 (p=0) or 3 (p=1) distinct source rows, so the
-        // duplicated taps are collapsed (their weights add): 2x2 / 2x3 / 3x2 / 3x3 gather taps instead of 16 per phase
+        // duplicated taps are collapsed (their weights add): 2x2 / 2x3 / 3x2 / 3x3 distinct source offsets instead of 16 taps per
+        // phase. Every phase is laid out on the SAME 3 x 3 offset grid (an offset a phase lacks gets mask 0 = zero weights): the four
+        // phases then share one tap pattern and one halo geometry and fold into ONE launch like the transposed convolution.
         d.GH = H; d.GW = W; d.OS = 2; d.OOY = py; d.OOX = px;
-        const int ny = py ? 3 : 2, nx = px ? 3 : 2;
+        const int ny = 3, nx = 3;
         p.dy0 = -1; p.dx0 = -1; p.hh = 8 + ny - 1; p.hw = 16 + nx - 1; p.ntaps = ny * nx;
         for (int iy = 0; iy < ny; ++iy)
           for (int ix = 0; ix < nx; ++ix) {
@@ -359,13 +361,13 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
   if (flags & TFC_EP_BIAS) REQUIRE(bias != nullptr, "bias is null");
   if (flags & TFC_EP_STATS) REQUIRE(stats != nullptr, "stats is null");
   int nph = num_phases(op, 0);
-  const bool fold = (op == TFC_OP_CONVT);                        // equal-shaped phases: fold all four into the grid of one launch
+  const bool fold = (op == TFC_OP_CONVT || op == TFC_OP_UPCONV);   // equal-shaped phases: fold all four into the grid of one launch
   if (fold) nph = 1;
   ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
   for (int ph = 0; ph < nph; ++ph) {
     TfcGather d;
     if (int e = build_desc(op, 0, ph, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, nullptr)) return e;
-    if (fold) { d.ph_n = 4; d.ph_d0 = 1; d.ph_oo = 1; }          // phase 0 descriptor + per-phase shifts (dy0 = py-1, OOY = py)
+    if (fold) { d.ph_n = 4; d.ph_d0 = (op == TFC_OP_CONVT) ? 1 : 0; d.ph_oo = 1; }   // phase 0 descriptor + per-phase shifts (convT: dy0 = py-1; both: OOY = py)
     if (int e = check_desc(d, dt)) return e;
     CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
   }

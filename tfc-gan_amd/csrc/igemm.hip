@@ -66,9 +66,7 @@ template <int R, int C, bool REV> struct TapPatRC {
 template <> struct TapPat<1> : TapPatRC<4, 4, false> {};   // conv / pad+conv, forward and dgrad
 template <> struct TapPat<2> : TapPatRC<2, 2, true> {};    // transposed-conv forward phases
 template <> struct TapPat<3> : TapPatRC<2, 2, false> {};   // transposed-conv dgrad parity planes, upsample-conv phase (0,0)
-template <> struct TapPat<4> : TapPatRC<2, 3, false> {};   // upsample-conv phases with collapsed taps
-template <> struct TapPat<5> : TapPatRC<3, 2, false> {};
-template <> struct TapPat<6> : TapPatRC<3, 3, false> {};
+template <> struct TapPat<6> : TapPatRC<3, 3, false> {};   // upsample-conv: every phase on the 3 x 3 source-offset grid
 
 #ifndef TFC_BD
 #define TFC_BD 4
@@ -1205,6 +1203,7 @@ hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const flo
 static int plane_pattern(const TfcPlane& p) {
   static const int R[7] = {0, 4, 2, 2, 2, 3, 3}, C[7] = {0, 4, 2, 2, 3, 2, 3}, REV[7] = {0, 0, 1, 0, 0, 0, 0};
   for (int pat = 1; pat <= 6; ++pat) {
+    if (pat == 4 || pat == 5) continue;                           // 2x3 / 3x2 grids are no longer produced (the upsample conv uses 3x3 for every phase)
     if (p.ntaps != R[pat] * C[pat]) continue;
     bool ok = true;
     for (int t = 0; t < p.ntaps && ok; ++t) {
@@ -1256,8 +1255,6 @@ static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const voi
     case 1: return launch_igemm_pat<T, MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
     case 2: return launch_igemm_pat<T, MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
     case 3: return launch_igemm_pat<T, MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-    case 4: return launch_igemm_pat<T, MT, NT, WM, WN, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-    case 5: return launch_igemm_pat<T, MT, NT, WM, WN, 5>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
     case 6: return launch_igemm_pat<T, MT, NT, WM, WN, 6>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
     default: return launch_igemm_pat<T, MT, NT, WM, WN, 0>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   }
