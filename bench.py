@@ -105,11 +105,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if os.environ.get("TFC_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: more ranks than cards
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("TFC_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the multi-rank path on ONE card (ranks share cuda:0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     T.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(42)                                # reference: torch.manual_seed(42), P16:61
