@@ -22,7 +22,7 @@ from .ops import DT_BF16
 
 class TrainStep:
     def __init__(self, generator, discriminator, lr=2e-4, b1=0.5, b2=0.999, eps=1e-8, compute_dtype=torch.bfloat16,
-                 fft_mode="patch", seed=0, bucket_bytes=32 << 20, lambda_gan=0.5, lambda_fft=0.01, lambda_trip=1.0):
+                 fft_mode="patch", seed=0, bucket_bytes=16 << 20, lambda_gan=0.5, lambda_fft=0.01, lambda_trip=1.0):
         dev = next(generator.parameters()).device
         if dev.type != "cuda":
             raise ops._lib.TfcError("TrainStep needs the modules on a CUDA/HIP device (no CPU fallback)")
