@@ -845,7 +845,13 @@ __global__ void __launch_bounds__(256) tfc_snb_mv_kernel(const SnBatch b) {
   const float* W = b.W[L] + (size_t)row * K;
   const float* v = b.v[L];
   float a = 0.f;
-  for (int k = lane; k < K; k += 64) a += W[k] * v[k];
+  if ((K & 3) == 0) {                                            // 16-byte loads (K = Cin * 16; every row start is 16-byte aligned)
+    const float4* W4 = reinterpret_cast<const float4*>(W);
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    for (int k = lane; k < (K >> 2); k += 64) { const float4 w = W4[k], x = v4[k]; a += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w; }
+  } else {
+    for (int k = lane; k < K; k += 64) a += W[k] * v[k];
+  }
   a = wave_sum(a);
   if (lane == 0) b.s[L][row] = a;
 }
@@ -897,7 +903,13 @@ __global__ void __launch_bounds__(256) tfc_snb_sigma_kernel(const SnBatch b, flo
   if (row < R) {
     const float* W = b.W[L] + (size_t)row * K;
     float a = 0.f;
-    for (int k = lane; k < K; k += 64) a += W[k] * vin[k];
+    if ((K & 3) == 0) {
+      const float4* W4 = reinterpret_cast<const float4*>(W);
+      const float4* v4 = reinterpret_cast<const float4*>(vin);
+      for (int k = lane; k < (K >> 2); k += 64) { const float4 w = W4[k], x = v4[k]; a += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w; }
+    } else {
+      for (int k = lane; k < K; k += 64) a += W[k] * vin[k];
+    }
     a = wave_sum(a) * inv;
     // u of this row: written by the mtv kernel of this call (power_iter) or the stored buffer
     part = a * b.u[L][row];
@@ -938,7 +950,16 @@ hipError_t tfc_launch_sn_step_batched(const SnBatch& b, float* ws_t, size_t t_by
 __global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* out) {
   __shared__ float red[4];
   float s = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += a[i] * b[i];
+  if ((n & 3) == 0) {
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (n >> 2); i += (long long)gridDim.x * 256) {
+      const float4 x = a4[i], y = b4[i];
+      s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += a[i] * b[i];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -1204,8 +1225,8 @@ hipError_t tfc_launch_sn_bwd(const float* G, const float* W, const float* u, con
   hipError_t e = hipMemsetAsync(dot_ws, 0, sizeof(float), st);
   if (e != hipSuccess) return e;
   const long long n = (long long)R * K;
-  int nb = (int)((n + 255) / 256);
-  if (nb > 1024) nb = 1024;
+  int nb = (int)((n + 1023) / 1024);
+  if (nb > 128) nb = 128;                                        // every workgroup ends in ONE atomic on the same address (~12 ns each, serialised)
   hipLaunchKernelGGL(tfc_dot_kernel, dim3(nb), dim3(256), 0, st, G, W, n, dot_ws);
   hipLaunchKernelGGL(tfc_sn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, u, v, sigma2, dot_ws, gout, R, K, accumulate);
   return hipGetLastError();
