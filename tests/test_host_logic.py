@@ -170,3 +170,20 @@ def test_checkpoint_helpers_and_stitch(tmp_path):
         assert torch.equal(grid[:, 3 * k:3 * k + 3, :64], f[:, :, y0:y0 + 64, x0:x0 + 64])
         assert torch.equal(grid[:, 3 * k:3 * k + 3, 64:], r[:, :, y0:y0 + 64, x0:x0 + 64])
     assert T.global_grid(f, r, f).shape == (2, 3, 768, 256)
+
+
+def test_zero_arena_hands_out_zeroed_disjoint_views():
+    """the per-step scratch arena: every view is zero when taken, views never overlap, begin() re-zeroes what was handed out"""
+    from tfc_gan_amd import ops
+    a = ops.ZeroArena(torch.device("cpu"), nfloats=1024)
+    a.begin()
+    v1, v2 = a.take((3, 5)), a.take((64,))
+    assert v1.abs().sum() == 0 and v2.abs().sum() == 0
+    v1.fill_(1.0); v2.fill_(2.0)
+    assert v1.sum() == 15 and v2.sum() == 128                   # disjoint
+    assert v1.data_ptr() % 16 == 0 and v2.data_ptr() % 16 == 0
+    big = a.take((4096,))                                        # does not fit: falls back to a fresh zero tensor
+    assert big.numel() == 4096 and big.abs().sum() == 0
+    a.begin()
+    w = a.take((3, 5))
+    assert w.data_ptr() == v1.data_ptr() and w.abs().sum() == 0
