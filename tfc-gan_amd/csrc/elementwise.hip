@@ -1059,15 +1059,45 @@ __global__ void __launch_bounds__(256)
 tfc_head_fwd_kernel(const T* __restrict__ x, int x_pitch, const float* __restrict__ w, T* __restrict__ y, int y_pitch,
                     int N, int H, int W, int C) {
   constexpr int UE = ElemTraits<T>::UE;
-  extern __shared__ __attribute__((aligned(16))) float wl[];      // [16 taps][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int npix = N * H * W;
+  const int CV = C / UE;                                          // 16-byte units per pixel
+  if (CV <= 64) {
+    // one unit per lane: the lane keeps ITS channels' 16 filter taps in registers for the whole launch (torch layout [c][16]: UE * 16
+    // contiguous floats per lane, streamed once) -- no LDS, no per-workgroup transpose of the 32 KB filter
+    float wr[UE][16];
+    const bool act = lane < CV;
+#pragma unroll
+    for (int e = 0; e < UE; ++e)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 f = act ? *reinterpret_cast<const float4*>(w + ((size_t)(lane * UE + e)) * 16 + q4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wr[e][q4 * 4 + 0] = f.x; wr[e][q4 * 4 + 1] = f.y; wr[e][q4 * 4 + 2] = f.z; wr[e][q4 * 4 + 3] = f.w;
+      }
+    for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
+      const int n = pix / (H * W), rem = pix - n * H * W;
+      const int oy = rem / W, ox = rem - oy * W;
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int iy = oy + (t >> 2) - 2, ix = ox + (t & 3) - 2;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W || !act) continue;   // wave-uniform apart from the idle lanes
+        float v[UE];
+        unpack16<T>(*reinterpret_cast<const uint4*>(x + ((size_t)(n * H + iy) * W + ix) * x_pitch + lane * UE), v);
+#pragma unroll
+        for (int e = 0; e < UE; ++e) acc += v[e] * wr[e][t];
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) ElemTraits<T>::st(y + (size_t)pix * y_pitch, acc);
+    }
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // [16 taps][C]  (wide inputs: filter transposed in LDS)
   for (int i = threadIdx.x; i < 16 * C; i += 256) {
     const int c = i >> 4, t = i & 15;                             // torch layout index c*16 + t
     wl[t * C + c] = w[i];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int npix = N * H * W;
-  const int CV = C / UE;                                          // 16-byte units per pixel
   for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += gridDim.x * 4) {
     const int n = pix / (H * W), rem = pix - n * H * W;
     const int oy = rem / W, ox = rem - oy * W;
@@ -1275,8 +1305,9 @@ hipError_t tfc_launch_cast(int dt, int to_f32, const void* x, void* y, long long
 hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st) {
   const int npix = N * H * W;
   int nb = (npix + 3) / 4;
-  if (nb > 1024) nb = 1024;
-  const size_t lds = (size_t)16 * C * sizeof(float);
+  if (nb > 512) nb = 512;                                        // the filter is loaded once per wave: few, long-lived workgroups
+  const int ue = dt == TFC_DT_BF16 ? 8 : 4;
+  const size_t lds = (C / ue <= 64) ? 0 : (size_t)16 * C * sizeof(float);
   if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_head_fwd_kernel<bf16_t>), dim3(nb), dim3(256), lds, st, (const bf16_t*)x, x_pitch, w, (bf16_t*)y, y_pitch, N, H, W, C);
   else hipLaunchKernelGGL((tfc_head_fwd_kernel<float>), dim3(nb), dim3(256), lds, st, (const float*)x, x_pitch, w, (float*)y, y_pitch, N, H, W, C);
   return hipGetLastError();
