@@ -66,6 +66,12 @@ int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N
  * (w: torch-layout fp32 [1][C][4][4], y: [N][H][W][y_pitch] channel 0). Same result as tfc_conv_fwd(TFC_OP_PADCONV, Cout=1). */
 int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* w,
                           void* y, int y_pitch);
+/* generator head, P16:150-157: nn.Upsample(2) -> nn.ZeroPad2d((1,0,1,0)) -> nn.Conv2d(128, Cout <= 4, 4, padding=1) -> nn.Tanh, forward,
+ * bf16 only: x [N][H][W][x_pitch] (128 channels), w torch-layout fp32 [Cout][128][4][4], out fp32 NCHW [N][Cout][2H][2W].
+ * Same result as tfc_conv_fwd(TFC_OP_UPCONV, TFC_EP_BIAS | TFC_EP_TANH_NCHW); the four sub-pixel phases share one 16-wide MFMA tile. */
+int tfc_upconv_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const float* w,
+                        const float* bias, float* out_nchw);
+
 /* ---- input gradient: dx = oscale * op^T(dy) (flags: TFC_EP_ACCUM) ------------------------------------------------ */
 int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
                    const void* packed, void* dx, int dx_pitch, const float* oscale, int flags);

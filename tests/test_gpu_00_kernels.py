@@ -186,6 +186,25 @@ def test_upconv_tanh_nchw_head():
         assert (out.cpu() - want).abs().max().item() <= (1e-5 if dt == DT_F32 else 1e-2)
 
 
+@pytest.mark.parametrize("N,H,W,Cout,with_bias", [(2, 16, 16, 3, True), (1, 9, 10, 3, True), (3, 21, 40, 1, False), (5, 64, 64, 4, True)])
+def test_generator_head_kernel(N, H, W, Cout, with_bias):
+    """tfc_upconv_head_fwd (phases as columns of a 16-wide MFMA tile, channel chunks over the waves, persistent) against torch and
+    against the gather-GEMM path it replaces; ragged tiles, several tiles per workgroup"""
+    dt = DT_BF16
+    x = q(rnd((N, 128, H, W), 5), dt)
+    w = rnd((Cout, 128, 4, 4), 6, 0.02)
+    b = rnd((Cout,), 7, 0.1) if with_bias else None
+    want = torch.tanh(ref_conv(ops.OP_UPCONV, x, w, b))
+    xv = to_view(x, dt)
+    out = torch.full((N, Cout, 2 * H, 2 * W), 7.0, dtype=torch.float32, device=DEV)
+    ops.upconv_head_fwd(dt, xv, w.to(DEV), None if b is None else b.to(DEV), out)
+    assert (out.cpu() - want).abs().max().item() <= 1e-2            # collapsed weights are summed in fp32, rounded to bf16 once
+    old = torch.empty_like(out)
+    ops.conv_fwd(dt, ops.OP_UPCONV, xv, 128, Cout, ops.pack_weight(dt, ops.OP_UPCONV, 0, w.to(DEV), 128, Cout), None,
+                 bias=None if b is None else b.to(DEV), out_nchw=old)
+    assert (out - old).abs().max().item() <= 2e-5                    # same bf16 operands, fp32 accumulation in a different order
+
+
 def oracle_act(x, norm, slope, pool, mask=None, drop_p=0.0):
     y = F.instance_norm(x, eps=1e-5) if norm else x
     y = torch.where(y > 0, y, y * slope)

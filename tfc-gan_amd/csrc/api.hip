@@ -27,6 +27,7 @@ size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
+hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int W, const float* w, const float* bias, int Cout, float* out, hipStream_t st);
 bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
                                    int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err);
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
@@ -371,6 +372,17 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
     if (int e = check_desc(d, dt)) return e;
     CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
   }
+  return 0;
+}
+
+extern "C" int tfc_upconv_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const float* w,
+                                  const float* bias, float* out_nchw) {
+  REQUIRE(dt == TFC_DT_BF16 && Cin == 128 && Cout >= 1 && Cout <= 4, "tfc_upconv_head_fwd: bf16, Cin == 128, Cout <= 4 only (use tfc_conv_fwd(TFC_OP_UPCONV) otherwise)");
+  REQUIRE(x && w && out_nchw && N > 0 && H > 1 && W > 1 && x_pitch >= 128 && x_pitch % 8 == 0, "bad args");
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(w, "w")) return e;
+  ProfScope prof(0, conv_flop(TFC_OP_UPCONV, N, H, W, Cin, Cout), (hipStream_t)stream);
+  CHECK_HIP(tfc_launch_upconv_head(x, x_pitch, N, H, W, w, bias, Cout, out_nchw, (hipStream_t)stream), "tfc_upconv_head_fwd");
   return 0;
 }
 

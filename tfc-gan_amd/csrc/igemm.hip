@@ -452,6 +452,177 @@ tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Generator head (P16:150-157: Upsample(x2 nearest) -> ZeroPad2d(1,0,1,0) -> Conv2d(128, C<=4, 4, padding=1) -> Tanh), forward, bf16.
+// The gather-GEMM spends a 32-wide MFMA tile on 3 output channels, once per sub-pixel phase. Here the four phases of an INPUT pixel
+// share its 3 x 3 neighbourhood, so they become COLUMNS of one 16-wide tile:  col = phase * 4 + oc  (12 of 16 used),
+//   out[2a+py][2b+px][oc] = tanh(bias[oc] + sum_{r,c,ci} x[a-1+r][b-1+c][ci] * Wc[py,px][r][c][ci][oc]),
+// Wc = the filter taps that collapse onto source offset (r,c) in that phase, summed (zero where a phase lacks the offset).
+// K = 9 offsets x 128 channels = 36 steps of v_mfma_f32_16x16x32_bf16, split over the workgroup's four waves BY CHANNEL CHUNK: wave w
+// owns channels 32w..32w+31 for the whole 8 x 16 tile, so its nine B fragments (built once from the fp32 filter, weights-stationary,
+// persistent workgroups) cost 36 VGPRs, and its eight 16 x 16 accumulators are partial sums that meet in LDS. The whole
+// 10 x 18 x 128 halo of a tile is staged in LDS (pixel stride 256 + 16 B); the next tile's halo is requested before this tile's
+// stores are issued, so the wait for it never includes them (vmcnt retires in order). Output: tanh, fp32 NCHW, 8-byte stores that
+// form whole 128-byte row segments per 16 lanes.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tfc_upconv_head_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, const float* __restrict__ w, const float* __restrict__ bias,
+                       int Cout, float* __restrict__ out, int nimg, int nwork) {
+  constexpr int HH = TFC_TILE_H + 2, HW = TFC_TILE_W + 2, NPIX = HH * HW;      // 10 x 18 halo
+  constexpr int PS = 256 + 16;                                   // LDS bytes per halo pixel: 128 channels + pad (conflict-free 16-lane reads)
+  constexpr int NHV = (NPIX * 16 + 255) / 256;                   // 16-byte halo units per thread (12)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* part = reinterpret_cast<float*>(smem);                  // [4 waves][8 ty][16 tx][16 cols] partial sums: reuses the halo bytes
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kg = lane >> 4;
+  const int ph = col >> 2, oc = col & 3, py = ph >> 1, px = ph & 1;
+  const int G = gridDim.x;
+  const int tiles_y = (IH + TFC_TILE_H - 1) / TFC_TILE_H, tiles_x = (IW + TFC_TILE_W - 1) / TFC_TILE_W;
+  const int OH = 2 * IH, OW = 2 * IW;
+
+  // ---- B fragments of this wave's channel chunk: bw[r * 3 + c], element j <-> ci = wave * 32 + kg * 8 + j ----
+  uint4 bw[9];
+  {
+    const bool real = oc < Cout;
+    float f[9][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = wave * 32 + kg * 8 + j;
+      float t[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 v = real ? *reinterpret_cast<const float4*>(w + ((size_t)oc * 128 + ci) * 16 + q4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        t[q4 * 4 + 0] = v.x; t[q4 * 4 + 1] = v.y; t[q4 * 4 + 2] = v.z; t[q4 * 4 + 3] = v.w;
+      }
+      // filter rows ky -> source row r: py = 0: {0,1} -> 0, {2,3} -> 1;  py = 1: {0} -> 0, {1,2} -> 1, {3} -> 2   (same for columns)
+      float rr[3][4];
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        rr[0][kx] = py ? t[kx] : t[kx] + t[4 + kx];
+        rr[1][kx] = py ? t[4 + kx] + t[8 + kx] : t[8 + kx] + t[12 + kx];
+        rr[2][kx] = py ? t[12 + kx] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        f[r * 3 + 0][j] = px ? rr[r][0] : rr[r][0] + rr[r][1];
+        f[r * 3 + 1][j] = px ? rr[r][1] + rr[r][2] : rr[r][2] + rr[r][3];
+        f[r * 3 + 2][j] = px ? rr[r][3] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 9; ++o) bw[o] = pack16<bf16_t>(f[o]);
+  }
+
+  auto decode = [&](int wk, int& img, int& a0, int& b0) {
+    int tile = tfc_xcd_remap(wk, nwork);
+    const int txb = tile % tiles_x; tile /= tiles_x;
+    const int tyb = tile % tiles_y;
+    img = tile / tiles_y;
+    a0 = tyb * TFC_TILE_H; b0 = txb * TFC_TILE_W;
+  };
+  uint4 hv[NHV];
+  auto halo_load = [&](int img, int a0, int b0) {
+#pragma unroll
+    for (int i = 0; i < NHV; ++i) {
+      const int idx = tid + i * 256;                             // pixel * 16 + unit
+      const int pix = idx >> 4, u = idx & 15;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int y = a0 - 1 + hy, xx = b0 - 1 + hx;
+      hv[i] = make_uint4(0, 0, 0, 0);
+      if (pix < NPIX && y >= 0 && y < IH && xx >= 0 && xx < IW)
+        hv[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(img * IH + y) * IW + xx) * x_pitch + u * 8);
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NHV; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < NPIX * 16) *reinterpret_cast<uint4*>(smem + (idx >> 4) * PS + (idx & 15) * 16) = hv[i];
+    }
+  };
+  // reduction / store role of this thread: output pixel pair (2*rty + rh, 2*rtx .. 2*rtx+1), i.e. columns rh*8 .. rh*8+7 = phases (rh,0), (rh,1)
+  const int rty = tid >> 5, rtx = (tid >> 1) & 15, rh = tid & 1;
+  float bz[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bz[c] = (bias && c < Cout) ? bias[c] : 0.f;
+
+  int wk = blockIdx.x;
+  int img, a0, b0;
+  decode(wk, img, a0, b0);
+  halo_load(img, a0, b0);
+  halo_store();
+  __syncthreads();
+
+  for (;;) {
+    f32x4_t acc[8];
+#pragma unroll
+    for (int ty = 0; ty < 8; ++ty) acc[ty] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // A fragment: lane (row = lane & 15 -> tile column tx, kg) reads 16 B of pixel (ty + r, tx + c), channels wave*32 + kg*8 ..
+    const unsigned char* abase = smem + col * PS + wave * 64 + kg * 16;
+#pragma unroll
+    for (int ty = 0; ty < 8; ++ty)
+#pragma unroll
+      for (int o = 0; o < 9; ++o) {
+        const uint4 a = *reinterpret_cast<const uint4*>(abase + ((ty + o / 3) * HW + o % 3) * PS);
+        acc[ty] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[o]), acc[ty], 0, 0, 0);
+      }
+    const bool has1 = (wk + G) < nwork;
+    __syncthreads();                                             // every wave is done with this tile's halo: its bytes become the partial sums
+    int n_img = 0, n_a0 = 0, n_b0 = 0;
+    if (has1) { decode(wk + G, n_img, n_a0, n_b0); halo_load(n_img, n_a0, n_b0); }   // requested BEFORE the stores below (vmcnt is in order)
+    // D layout: col = lane & 15 = (phase, oc); row = 4 * (lane >> 4) + j = tx
+#pragma unroll
+    for (int ty = 0; ty < 8; ++ty)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[((wave * 8 + ty) * 16 + 4 * kg + j) * 16 + col] = acc[ty][j];
+    __syncthreads();
+    {
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        const float4* pp = reinterpret_cast<const float4*>(part + ((wv * 8 + rty) * 16 + rtx) * 16 + rh * 8);
+        const float4 u0 = pp[0], u1 = pp[1];
+        s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
+        s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+      }
+      const float v0[4] = {s0.x, s0.y, s0.z, s0.w}, v1[4] = {s1.x, s1.y, s1.z, s1.w};   // px = 0 / px = 1, channel oc
+      const int oy = 2 * (a0 + rty) + rh, ox = 2 * (b0 + rtx);
+      if (oy < OH && ox < OW) {
+        for (int c = 0; c < Cout; ++c) {
+          float* dst = out + (((size_t)img * Cout + c) * OH + oy) * OW + ox;
+          const float e0 = tanhf(v0[c] + bz[c]), e1 = tanhf(v1[c] + bz[c]);
+          if (ox + 1 < OW && (OW & 1) == 0) *reinterpret_cast<float2*>(dst) = make_float2(e0, e1);
+          else { dst[0] = e0; if (ox + 1 < OW) dst[1] = e1; }
+        }
+      }
+    }
+    if (!has1) break;
+    __syncthreads();                                             // partial sums consumed: the bytes become the next halo
+    halo_store();
+    __syncthreads();
+    wk += G; img = n_img; a0 = n_a0; b0 = n_b0;
+  }
+}
+hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int W, const float* w, const float* bias, int Cout, float* out,
+                                  hipStream_t st) {
+  const int lds = (TFC_TILE_H + 2) * (TFC_TILE_W + 2) * (256 + 16);   // 48,960 B >= the 32 KiB of partial sums that reuse it
+  static int grid_cap = 0;
+  if (!grid_cap) {
+    int occ = 0, dev = 0, ncu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_upconv_head_kernel, 256, (size_t)lds);
+    if (e != hipSuccess) return e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    grid_cap = (occ < 1 ? 1 : occ) * ncu;
+  }
+  const int nwork = N * ((H + TFC_TILE_H - 1) / TFC_TILE_H) * ((W + TFC_TILE_W - 1) / TFC_TILE_W);
+  hipLaunchKernelGGL(tfc_upconv_head_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), lds, st, (const bf16_t*)x, H, W, x_pitch, w, bias,
+                     Cout, out, N, nwork);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight-gradient GEMM for 2 x 2-tap planes (bf16): the sub-pixel phases of the transposed convolution and phase (0,0) of the
 // upsample-conv. With only four taps the generic kernel gives each wave ONE tap (3 transposing LDS reads per MFMA); here a
 // workgroup owns 64 n x 64 c and wave (nh, ch) owns the 32 n x 32 c quadrant for ALL four taps: the B fragments of halo rows

@@ -148,8 +148,11 @@ class GeneratorCore:
             ctx.uins.append(cur)
             cur = View(cat[name].t, cat[name].t.shape[3], 0)
         fake = torch.empty((N, self.channels, S, S), dtype=torch.float32, device=dev)
-        ops.conv_fwd(dt, OP_UPCONV, cur, 128, self.channels, self.packed["final"]["fwd"], None, bias=self.params["final.2.bias"],
-                     out_nchw=fake)
+        if dt == DT_BF16 and self.channels <= 4:                 # phases as columns of one 16-wide MFMA tile, filter in registers
+            ops.upconv_head_fwd(dt, cur, self.params["final.2.weight"], self.params["final.2.bias"], fake)
+        else:
+            ops.conv_fwd(dt, OP_UPCONV, cur, 128, self.channels, self.packed["final"]["fwd"], None, bias=self.params["final.2.bias"],
+                         out_nchw=fake)
         ctx.u5 = cur
         ctx.fake = fake
         if not save:

@@ -193,6 +193,13 @@ def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stat
           "tfc_conv_fwd")
 
 
+def upconv_head_fwd(dt, x: View, w, bias, out_nchw):
+    """generator head (upsample + pad + conv(128 -> C<=4) + tanh), bf16: x NHWC View with 128 channels, w torch-layout fp32"""
+    Cout = w.shape[0]
+    check(lib().tfc_upconv_head_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, 128, Cout, _p(w), _p(bias), _p(out_nchw)),
+          "tfc_upconv_head_fwd")
+
+
 def patchgan_head_fwd(dt, x: View, w, y: View):
     check(lib().tfc_patchgan_head_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, x.C, _p(w), y.ptr, y.pitch), "tfc_patchgan_head_fwd")
 
