@@ -72,6 +72,13 @@ int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int 
 int tfc_upconv_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const float* w,
                         const float* bias, float* out_nchw);
 
+/* input gradient of the FIRST discriminator convolution (nn.Conv2d(Cin, 64, 4, stride 1, padding 1), P16:188) w.r.t. its first `nch`
+ * (<= 4) input channels -- the generated image inside cat(img_A, img_B), P16:205 -- written as fp32 NCHW [N][nch][H][W]; bf16 only.
+ * dy: [N][H-1][W-1][dy_pitch] (64 channels), w: torch-layout fp32 [64][Cin][4][4], oscale: nullable device scalar (1/sigma).
+ * Same numbers as tfc_conv_dgrad(TFC_OP_CONV) + tfc_unpack_nchw restricted to those channels. */
+int tfc_conv_dgrad_image(void* stream, int dt, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout, const float* w,
+                         const float* oscale, int nch, float* dx_nchw);
+
 /* ---- input gradient: dx = oscale * op^T(dy) (flags: TFC_EP_ACCUM) ------------------------------------------------ */
 int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout,
                    const void* packed, void* dx, int dx_pitch, const float* oscale, int flags);

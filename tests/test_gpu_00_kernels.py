@@ -205,6 +205,22 @@ def test_generator_head_kernel(N, H, W, Cout, with_bias):
     assert (out - old).abs().max().item() <= 2e-5                    # same bf16 operands, fp32 accumulation in a different order
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 16, 16), (1, 37, 50), (5, 96, 64)])
+def test_first_conv_dgrad_image(N, H, W):
+    """tfc_conv_dgrad_image (four output rows packed into the columns of a 16-wide MFMA tile) against autograd on bf16-rounded operands"""
+    dt, Cin, Cout, nch, osc = DT_BF16, 6, 64, 3, 0.41
+    x = rnd((N, Cin, H, W), 21).requires_grad_(True)
+    w = rnd((Cout, Cin, 4, 4), 22, 0.1)
+    wq = q(w, dt)
+    y = F.conv2d(x, wq, padding=1)
+    go = q(rnd(tuple(y.shape), 23), dt)
+    (gx,) = torch.autograd.grad(y, x, go)
+    got = ops.conv_dgrad_image(dt, to_view(go, dt), N, H, W, Cin, w.to(DEV), torch.tensor([osc], device=DEV), nch).cpu()
+    want = gx[:, :nch] * osc
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= tol(dt, want.abs().max().item())
+
+
 def oracle_act(x, norm, slope, pool, mask=None, drop_p=0.0):
     y = F.instance_norm(x, eps=1e-5) if norm else x
     y = torch.where(y > 0, y, y * slope)

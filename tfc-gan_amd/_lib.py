@@ -62,6 +62,7 @@ PROTOTYPES = {
                                  _vp, _c.POINTER(_i)]),
     "tfc_conv_pack_planned": (_i, [_vp, _i, _vp, _i, _i]),
     "tfc_conv_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    "tfc_conv_dgrad_image": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "tfc_upconv_head_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tfc_patchgan_head_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i]),
     "tfc_conv_dgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i]),

@@ -27,6 +27,7 @@ size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
+hipError_t tfc_launch_dgrad_rows4(const void* dy, int dy_pitch, int N, int H, int W, const float* w, int Cin, const float* oscale, int NC, float* dx, hipStream_t st);
 hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int W, const float* w, const float* bias, int Cout, float* out, hipStream_t st);
 bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
                                    int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err);
@@ -372,6 +373,16 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
     if (int e = check_desc(d, dt)) return e;
     CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
   }
+  return 0;
+}
+
+extern "C" int tfc_conv_dgrad_image(void* stream, int dt, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout, const float* w,
+                                   const float* oscale, int nch, float* dx_nchw) {
+  REQUIRE(dt == TFC_DT_BF16 && Cout == 64 && Cin >= 1 && nch >= 1 && nch <= 4 && nch <= Cin, "tfc_conv_dgrad_image: bf16, Cout == 64, nch <= min(4, Cin) only");
+  REQUIRE(dy && w && dx_nchw && N > 0 && H > 4 && W > 4 && dy_pitch >= 64 && dy_pitch % 8 == 0, "bad args");
+  if (int e = check_ptr16(dy, "dy")) return e;
+  ProfScope prof(0, 2.0 * N * (H - 1.0) * (W - 1.0) * nch * Cout * 16.0, (hipStream_t)stream);
+  CHECK_HIP(tfc_launch_dgrad_rows4(dy, dy_pitch, N, H, W, w, Cin, oscale, nch, dx_nchw, (hipStream_t)stream), "tfc_conv_dgrad_image");
   return 0;
 }
 

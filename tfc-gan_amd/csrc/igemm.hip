@@ -604,6 +604,148 @@ tfc_upconv_head_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch
     wk += G; img = n_img; a0 = n_a0; b0 = n_b0;
   }
 }
+// ---------------------------------------------------------------------------------------------------
+// Input gradient of discriminator block 1 (P16:188: SN-Conv2d(6, 64, 4, 1, 1)) w.r.t. the generated image, bf16:
+//   dx[iy][ix][ci] = (1/sigma) * sum_{ky,kx,co} dy[iy+1-ky][ix+1-kx][co] * W[co][ci][ky][kx]      for ci < NC <= 4
+// -- a GEMM with 3 useful columns. Four consecutive OUTPUT ROWS are packed into the columns of one 16-wide MFMA tile:
+//   col = delta * 4 + ci,  row = 16 consecutive ix,  K = (7 row offsets x 4 column offsets) x 64 co = 56 steps of 16x16x32,
+// where offset r' of the seven uses filter row ky = 3 - (r' - delta) (zero outside 0..3). The 56 k-steps are split over the four
+// waves (co chunk x offset half): 14 register-resident B fragments per wave, built once from the fp32 filter; partial sums meet in
+// LDS. Tile = 8 rows x 32 columns (4 MFMA subtiles), halo 11 x 35 pixels x 64 co in LDS; persistent workgroups, next halo requested
+// before the stores. Output: fp32 NCHW, NC channels (the layout the loss gradients are added in -- no NHWC round trip).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tfc_dgrad_rows4_kernel(const bf16_t* __restrict__ dy, int OHs, int OWs, int dy_pitch, const float* __restrict__ w, int Cin, const float* __restrict__ oscale,
+                       int NC, float* __restrict__ dx, int IH, int IW, int nimg, int nwork) {
+  constexpr int TR = 8, TC = 32, HH = TR + 3, HW = TC + 3, NPIX = HH * HW;      // 11 x 35 halo of dy
+  constexpr int PS = 128 + 16;                                   // LDS bytes per halo pixel: 64 co + pad (conflict-free 16-lane reads)
+  constexpr int NHV = (NPIX * 8 + 255) / 256;                    // 16-byte halo units per thread (13)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* part = reinterpret_cast<float*>(smem);                  // [4 waves][4 subtiles][16 rows][16 cols]: reuses the halo bytes
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kg = lane >> 4;
+  const int delta = col >> 2, ci = col & 3;
+  const int chunk = wave & 1, ohalf = wave >> 1;                 // this wave: co = chunk*32 .., offsets ohalf*14 .. ohalf*14+13
+  const int G = gridDim.x;
+  const int tiles_y = (IH + TR - 1) / TR, tiles_x = (IW + TC - 1) / TC;
+
+  uint4 bw[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int o = ohalf * 14 + i;                                // offset (r', s) = (o / 4, o % 4)
+    const int rp = o >> 2, sx = o & 3;
+    const int ky = 3 - (rp - delta), kx = 3 - sx;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = chunk * 32 + kg * 8 + j;
+      f[j] = (ky >= 0 && ky <= 3 && ci < NC) ? w[((size_t)co * Cin + ci) * 16 + ky * 4 + kx] : 0.f;
+    }
+    bw[i] = pack16<bf16_t>(f);
+  }
+  const float osc = oscale ? *oscale : 1.f;
+
+  auto decode = [&](int wk, int& img, int& a0, int& b0) {
+    int tile = tfc_xcd_remap(wk, nwork);
+    const int txb = tile % tiles_x; tile /= tiles_x;
+    const int tyb = tile % tiles_y;
+    img = tile / tiles_y;
+    a0 = tyb * TR; b0 = txb * TC;
+  };
+  uint4 hv[NHV];
+  auto halo_load = [&](int img, int a0, int b0) {
+#pragma unroll
+    for (int i = 0; i < NHV; ++i) {
+      const int idx = tid + i * 256;                             // pixel * 8 + unit
+      const int pix = idx >> 3, u = idx & 7;
+      const int hy = pix / HW, hx = pix - hy * HW;
+      const int y = a0 - 2 + hy, xx = b0 - 2 + hx;
+      hv[i] = make_uint4(0, 0, 0, 0);
+      if (pix < NPIX && y >= 0 && y < OHs && xx >= 0 && xx < OWs)
+        hv[i] = *reinterpret_cast<const uint4*>(dy + ((size_t)(img * OHs + y) * OWs + xx) * dy_pitch + u * 8);
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NHV; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < NPIX * 8) *reinterpret_cast<uint4*>(smem + (idx >> 3) * PS + (idx & 7) * 16) = hv[i];
+    }
+  };
+  // reduction / store role: output pixel (row rrow of 8, column rcol of 32) of the tile, all NC channels
+  const int rrow = tid >> 5, rcol = tid & 31;
+
+  int wk = blockIdx.x;
+  int img, a0, b0;
+  decode(wk, img, a0, b0);
+  halo_load(img, a0, b0);
+  halo_store();
+  __syncthreads();
+
+  for (;;) {
+    f32x4_t acc[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) acc[st] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // subtile st = (qy, xg): output rows 4*qy .. 4*qy+3, columns 16*xg .. +15; A fragment of offset (r', s): halo pixel (4*qy + r', 16*xg + row + s)
+    const unsigned char* abase = smem + col * PS + chunk * 64 + kg * 16;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int i = 0; i < 14; ++i) {
+        const int hp = (4 * (st >> 1)) * HW + 16 * (st & 1);     // compile-time part; the offset part depends on the wave's half
+        const int o = ohalf * 14 + i;
+        const uint4 a = *reinterpret_cast<const uint4*>(abase + (hp + (o >> 2) * HW + (o & 3)) * PS);
+        acc[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[i]), acc[st], 0, 0, 0);
+      }
+    const bool has1 = (wk + G) < nwork;
+    __syncthreads();                                             // halo consumed: its bytes become the partial sums
+    int n_img = 0, n_a0 = 0, n_b0 = 0;
+    if (has1) { decode(wk + G, n_img, n_a0, n_b0); halo_load(n_img, n_a0, n_b0); }   // requested BEFORE the stores below (vmcnt is in order)
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[((wave * 4 + st) * 16 + 4 * kg + j) * 16 + col] = acc[st][j];
+    __syncthreads();
+    {
+      const int st = (rrow >> 2) * 2 + (rcol >> 4);
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        const float4 u = *reinterpret_cast<const float4*>(part + ((wv * 4 + st) * 16 + (rcol & 15)) * 16 + (rrow & 3) * 4);
+        sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
+      }
+      const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+      const int iy = a0 + rrow, ix = b0 + rcol;
+      if (iy < IH && ix < IW)
+        for (int c = 0; c < NC; ++c) dx[(((size_t)img * NC + c) * IH + iy) * IW + ix] = v[c] * osc;
+    }
+    if (!has1) break;
+    __syncthreads();                                             // partial sums consumed: the bytes become the next halo
+    halo_store();
+    __syncthreads();
+    wk += G; img = n_img; a0 = n_a0; b0 = n_b0;
+  }
+}
+hipError_t tfc_launch_dgrad_rows4(const void* dy, int dy_pitch, int N, int H, int W, const float* w, int Cin, const float* oscale, int NC, float* dx,
+                                  hipStream_t st) {
+  const int lds = 11 * 35 * (128 + 16);                          // 55,440 B >= the 16 KiB of partial sums that reuse it
+  static int grid_cap = 0;
+  if (!grid_cap) {
+    int occ = 0, dev = 0, ncu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_dgrad_rows4_kernel, 256, (size_t)lds);
+    if (e != hipSuccess) return e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    grid_cap = (occ < 1 ? 1 : occ) * ncu;
+  }
+  const int nwork = N * ((H + 7) / 8) * ((W + 31) / 32);
+  hipLaunchKernelGGL(tfc_dgrad_rows4_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), lds, st, (const bf16_t*)dy, H - 1, W - 1, dy_pitch, w,
+                     Cin, oscale, NC, dx, H, W, N, nwork);
+  return hipGetLastError();
+}
+
 hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int W, const float* w, const float* bias, int Cout, float* out,
                                   hipStream_t st) {
   const int lds = (TFC_TILE_H + 2) * (TFC_TILE_W + 2) * (256 + 16);   // 48,960 B >= the 32 KiB of partial sums that reuse it

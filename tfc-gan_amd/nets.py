@@ -340,6 +340,10 @@ class DiscriminatorCore:
                 if hook:
                     hook(f"model.{i}.parametrizations.weight.original")
                     hook(f"model.{i}.bias")
+            if bi == 0 and need_input_grad and dt == DT_BF16 and self.channels <= 4 and cout == 64:
+                # gradient w.r.t. the generated image only (3 of the 6 input channels): rows-packed 16-wide MFMA kernel, fp32 NCHW out
+                self._ws = ws
+                return ops.conv_dgrad_image(dt, d_raw, N, xin.H, xin.W, cin, W, sigma2[1:], self.channels)
             if bi > 0 or need_input_grad:
                 g_in = new_act(N, xin.H, xin.W, xin.pitch, dt, dev)
                 ops.conv_dgrad(dt, OP_CONV, d_raw, N, xin.H, xin.W, cin, cout, self.head_packed[f"d{i}"], g_in, oscale=sigma2[1:])

@@ -193,6 +193,14 @@ def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stat
           "tfc_conv_fwd")
 
 
+def conv_dgrad_image(dt, dy: View, N, H, W, Cin, w, oscale, nch):
+    """first discriminator conv, gradient w.r.t. its first `nch` input channels as fp32 NCHW [N,nch,H,W] (bf16 path)"""
+    out = torch.empty((N, nch, H, W), dtype=torch.float32, device=dy.t.device)
+    check(lib().tfc_conv_dgrad_image(stream_ptr(), dt, dy.ptr, dy.pitch, N, H, W, Cin, w.shape[0], _p(w), _p(oscale), nch, _p(out)),
+          "tfc_conv_dgrad_image")
+    return out
+
+
 def upconv_head_fwd(dt, x: View, w, bias, out_nchw):
     """generator head (upsample + pad + conv(128 -> C<=4) + tanh), bf16: x NHWC View with 128 channels, w torch-layout fp32"""
     Cout = w.shape[0]
