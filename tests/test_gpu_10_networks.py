@@ -214,6 +214,21 @@ def test_full_size_properties_batch32():
     c = (w.double() * dw.double()).sum().item()
     scale = (y.t.double().pow(2).sum().sqrt() * go.t.double().pow(2).sum().sqrt()).item()
     assert abs(a - b) <= 2e-3 * scale and abs(a - c) <= 2e-3 * scale, (a, b, c, scale)
+    # the same identity for the two first-layer kernels at full size: weights-stationary conv (6 -> 64 @ 256x256) against the rows-packed
+    # input-gradient kernel (gradient w.r.t. the first 3 channels; the other input channels are zero here)
+    x6 = torch.zeros((N, 256, 256, 8), device=DEV)
+    x6[..., :3] = torch.randn((N, 256, 256, 3), device=DEV)
+    x6v = ops.View(x6.to(torch.bfloat16), 6)
+    w1 = (torch.randn(64, 6, 4, 4, device=DEV) * 0.1).to(torch.bfloat16).float()
+    y1 = ops.new_act(N, 255, 255, 64, dt, DEV)
+    ops.conv_fwd(dt, ops.OP_CONV, x6v, 6, 64, ops.pack_weight(dt, ops.OP_CONV, 0, w1, 6, 64), y1)
+    g1 = ops.new_act(N, 255, 255, 64, dt, DEV)
+    g1.t.copy_(torch.randn(g1.t.shape, device=DEV))
+    dx1 = ops.conv_dgrad_image(dt, g1, N, 256, 256, 6, w1, None, 3)                   # fp32 NCHW [N,3,256,256]
+    a1 = (y1.t.double() * g1.t.double()).sum().item()
+    b1 = (x6v.t[..., :3].double().permute(0, 3, 1, 2) * dx1.double()).sum().item()
+    scale1 = (y1.t.double().pow(2).sum().sqrt() * g1.t.double().pow(2).sum().sqrt()).item()
+    assert abs(a1 - b1) <= 2e-3 * scale1, (a1, b1, scale1)
     # triplet with r_k = k: exactly the margin; FFT loss of identical images: exactly 0
     l, d = ops.patch16_triplet(fake, B, list(range(16)))
     assert abs(l.item() - 1.0) < 1e-6 and d.abs().max().item() == 0.0
