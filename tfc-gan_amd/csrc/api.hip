@@ -421,7 +421,7 @@ struct TfcPackJob {
   void* wp;
   long long sn, sc;
   int NB32, Nreal, Creal, units;
-  int first_block, pad_;
+  int first_block, threads;
 };
 extern "C" size_t tfc_pack_plan_bytes(int nlayers) { return (size_t)nlayers * 4 * sizeof(TfcPackJob); }
 // fills plan_host with one job per (layer, pass, phase); returns the number of jobs (<0 on error) and the grid size in *nblocks
@@ -442,8 +442,9 @@ extern "C" int tfc_pack_plan_build(int dt, int nlayers, const int* ops, const in
       j.sn = wm.sn; j.sc = wm.sc; j.Nreal = wm.Nreal; j.Creal = wm.Creal;
       j.NB32 = tfc_nb32_padded(j.d.Nout);
       j.units = tfc_total_substeps(j.d, es_of(dt)) * j.NB32 * 64;
-      j.first_block = blk; j.pad_ = 0;
-      blk += (j.units + 255) / 256;
+      j.threads = j.NB32 * 32 * ((j.d.Cin_pad * es_of(dt)) / 16);   // one thread per (output channel, 16-byte channel unit)
+      j.first_block = blk;
+      blk += (j.threads + 255) / 256;
       ++nj;
     }
   }

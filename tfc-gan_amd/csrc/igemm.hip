@@ -1209,8 +1209,12 @@ struct TfcPackJob {
   uint4* wp;
   long long sn, sc;
   int NB32, Nreal, Creal, units;                                  // units = 16-byte units of this job
-  int first_block, pad_;                                          // first 256-thread workgroup of this job in the planned grid
+  int first_block, threads;                                       // first 256-thread workgroup of this job in the planned grid; its thread count
 };
+// One thread per (output channel n, 16-byte channel unit o): it reads the 16 filter taps of its UE (n, c) pairs ONCE -- 64 contiguous
+// bytes each, both torch layouts keep the taps innermost -- and emits one packed unit per gather tap (collapsed taps: the sum of
+// their filter taps). n runs fastest over the threads, so a wave's stores are 512-byte runs of the stream (lane field = n & 31).
+// The unit-per-thread gather this replaces fetched every 64-byte tap row sixteen times through L2 (195 us for the generator).
 template <typename T>
 __global__ void __launch_bounds__(256)
 tfc_pack_planned_kernel(const TfcPackJob* __restrict__ jobs, int njobs) {
@@ -1222,20 +1226,45 @@ tfc_pack_planned_kernel(const TfcPackJob* __restrict__ jobs, int njobs) {
     if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const TfcPackJob& j = jobs[lo];
-  const int idx = ((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
-  if (idx >= j.units) return;
-  int n, mask, c0;
-  tfc_pack_locate(j.d, ES, j.NB32, idx, &n, &mask, &c0);
-  float v[UE];
+  const int t = ((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  if (t >= j.threads) return;
+  const int Npad = j.NB32 * 32;
+  const int n = t % Npad, o = t / Npad;
+  const int PB = tfc_pb(j.d.Cin_pad, ES), UPP = PB >> 4;
+  const int cc = o / UPP, g = o - cc * UPP;
+  const int c0 = o * UE;
+  float row[UE][16];
 #pragma unroll
   for (int e = 0; e < UE; ++e) {
-    const int c = c0 + e;
-    float a = 0.f;
-    if (n < j.Nreal && c < j.Creal)
-      for (int m = mask; m; m &= m - 1) a += j.w[(long long)n * j.sn + (long long)c * j.sc + (__ffs(m) - 1)];
-    v[e] = a;
+    const bool ok = n < j.Nreal && c0 + e < j.Creal;
+    const float4* pr = reinterpret_cast<const float4*>(j.w + (long long)n * j.sn + (long long)(c0 + e) * j.sc);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 v = ok ? pr[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      row[e][q4 * 4 + 0] = v.x; row[e][q4 * 4 + 1] = v.y; row[e][q4 * 4 + 2] = v.z; row[e][q4 * 4 + 3] = v.w;
+    }
   }
-  j.wp[idx] = pack16<T>(v);
+  int per_chunk = 0;
+  for (int pl = 0; pl < j.d.nplanes; ++pl) per_chunk += tfc_nsub(j.d.plane[pl].ntaps, PB);
+  int gs_base = cc * per_chunk;
+  const int lane_lo = n & 31, nb = n >> 5;
+  for (int pl = 0; pl < j.d.nplanes; ++pl) {
+    const TfcPlane& p = j.d.plane[pl];
+    for (int tap = 0; tap < p.ntaps; ++tap) {
+      const int u = tap * UPP + g;
+      const int mask = p.tap_mask[tap];
+      float v[UE];
+#pragma unroll
+      for (int e = 0; e < UE; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) a += ((mask >> sl) & 1) ? row[e][sl] : 0.f;
+        v[e] = a;
+      }
+      j.wp[((size_t)(gs_base + (u >> 1)) * j.NB32 + nb) * 64 + lane_lo + 32 * (u & 1)] = pack16<T>(v);
+    }
+    gs_base += tfc_nsub(p.ntaps, PB);
+  }
 }
 hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st) {
   if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_pack_planned_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
