@@ -1494,20 +1494,29 @@ tfc_wgrad_reduce_kernel(const float4* __restrict__ slab, float* acc, const TfcPl
   }
 }
 
-// fp32 accumulator [16 slots][Nn][Cw] -> torch-layout gradient  grad[n*sn + c*sc + slot]
+// fp32 accumulator [16 slots][Nn][Cw] -> torch-layout gradient  grad[n*sn + c*sc + slot].  One thread per (n, c): its 16 reads are
+// coalesced across the wave slot by slot (c runs over the lanes), its 16 results are 64 contiguous bytes (both torch layouts keep
+// the taps innermost), and the accumulator is re-zeroed with the same coalesced pattern.
 __global__ void __launch_bounds__(256)
 tfc_wgrad_finish_kernel(float* __restrict__ acc, float* __restrict__ grad, int Nn, int Cw,
                         long long sn, long long sc, int accumulate, int total) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = blockIdx.x * 256 + threadIdx.x;                // n * Cw + c
   if (idx >= total) return;
-  const int slot = idx & 15;
-  const int rest = idx >> 4;
-  const int c = rest % Cw, n = rest / Cw;
-  float* pa = acc + ((size_t)slot * Nn + n) * Cw + c;
-  const float v = *pa;
-  *pa = 0.f;                                                      // leave the accumulator zeroed for the next wgrad
-  float* g = grad + (long long)n * sn + (long long)c * sc + slot;
-  *g = accumulate ? (*g + v) : v;
+  const int c = idx % Cw, n = idx / Cw;
+  float v[16];
+#pragma unroll
+  for (int slot = 0; slot < 16; ++slot) {
+    float* pa = acc + (size_t)slot * total + idx;
+    v[slot] = *pa;
+    *pa = 0.f;                                                    // leave the accumulator zeroed for the next wgrad
+  }
+  float4* g = reinterpret_cast<float4*>(grad + (long long)n * sn + (long long)c * sc);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    float4 o = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+    if (accumulate) { const float4 p = g[q4]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    g[q4] = o;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1737,7 +1746,7 @@ hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const vo
 }
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
                                    int accumulate, hipStream_t st) {
-  const int total = Nn * Cw * 16;
+  const int total = Nn * Cw;                                      // one thread per (n, c): all 16 taps
   hipLaunchKernelGGL(tfc_wgrad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, acc, grad, Nn, Cw, sn, sc,
                      accumulate, total);
   return hipGetLastError();
