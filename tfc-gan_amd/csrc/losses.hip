@@ -23,29 +23,46 @@ tfc_triplet16_kernel(const float* __restrict__ fake, const float* __restrict__ r
   const long long nrows = (long long)N * C * 256 * 4;
   const float scale = 1.f / (16.f * (float)N * (float)C * 64.f);
   float lsum = 0.f;
-  for (long long row = (long long)blockIdx.x * 4 + w; row < nrows; row += (long long)gridDim.x * 4) {
-    const int kx = (int)(row & 3);
-    const long long r2 = row >> 2;
-    const int y = (int)(r2 & 255);
-    const long long nc = r2 >> 8;                                // n*C + c
-    const int k = (y >> 6) * 4 + kx;
-    const int rk = neg.r[k];
-    const size_t plane = (size_t)nc * 65536;
-    const size_t ia = plane + (size_t)y * 256 + kx * 64 + lane;
-    const size_t in_ = plane + (size_t)((rk >> 2) * 64 + (y & 63)) * 256 + (rk & 3) * 64 + lane;
-    const float a = fake[ia], p = real[ia], ng = real[in_];
-    const float dp = a - p + eps, dn = a - ng + eps;
-    const float sp = wave_sum(dp * dp), sn = wave_sum(dn * dn);
-    const float dap = sqrtf(sp), dan = sqrtf(sn);
-    const float hinge = margin + dap - dan;
-    if (hinge > 0.f) {
-      lsum += hinge;                                             // identical on all lanes
-      if (dfake) {
-        const float g = (dap > 0.f ? dp / dap : 0.f) - (dan > 0.f ? dn / dan : 0.f);
-        dfake[ia] = g * scale * gscale;
+  // four rows per iteration: their loads are issued together (one dependent load -> reduce -> store chain per row leaves the
+  // memory pipeline idle most of the time)
+  constexpr int R = 4;
+  const long long stride = (long long)gridDim.x * 4;
+  for (long long row0 = (long long)blockIdx.x * 4 + w; row0 < nrows; row0 += stride * R) {
+    float a[R], p[R], ng[R];
+    size_t ia[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long long row = row0 + r * stride;
+      ok[r] = row < nrows;
+      const long long rw = ok[r] ? row : row0;
+      const int kx = (int)(rw & 3);
+      const long long r2 = rw >> 2;
+      const int y = (int)(r2 & 255);
+      const long long nc = r2 >> 8;                              // n*C + c
+      const int k = (y >> 6) * 4 + kx;
+      const int rk = neg.r[k];
+      const size_t plane = (size_t)nc * 65536;
+      ia[r] = plane + (size_t)y * 256 + kx * 64 + lane;
+      const size_t in_ = plane + (size_t)((rk >> 2) * 64 + (y & 63)) * 256 + (rk & 3) * 64 + lane;
+      a[r] = fake[ia[r]]; p[r] = real[ia[r]]; ng[r] = real[in_];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!ok[r]) continue;                                      // wave-uniform
+      const float dp = a[r] - p[r] + eps, dn = a[r] - ng[r] + eps;
+      const float sp = wave_sum(dp * dp), sn = wave_sum(dn * dn);
+      const float dap = sqrtf(sp), dan = sqrtf(sn);
+      const float hinge = margin + dap - dan;
+      if (hinge > 0.f) {
+        lsum += hinge;                                           // identical on all lanes
+        if (dfake) {
+          const float g = (dap > 0.f ? dp / dap : 0.f) - (dan > 0.f ? dn / dan : 0.f);
+          dfake[ia[r]] = g * scale * gscale;
+        }
+      } else if (dfake) {
+        dfake[ia[r]] = 0.f;
       }
-    } else if (dfake) {
-      dfake[ia] = 0.f;
     }
   }
   if (lane == 0) red[w] = lsum;
