@@ -165,6 +165,15 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
     for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const uint4*>(pw + laneoff + nt * 1024);
   };
 
+  // epilogue scalars, requested NOW: a load issued at the start of the epilogue would stall every workgroup for a full memory round trip
+  const float osc = oscale ? *oscale : 1.f;                      // spectral norm: conv(x, W / sigma) = conv(x, W) / sigma
+  float bvs[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (nb0 + nt) * 32 + r;
+    bvs[nt] = ((flags & TFC_EP_BIAS) && n < d.Nout) ? bias[n] : 0.f;
+  }
+
   if constexpr (PAT != 0) {
     constexpr int NSR = TapPat<PAT>::COLS * 2;                   // k-substeps per filter row (2 per tap: 4 units of 16 B)
     static_assert(NSR % BD == 0, "register ring must realign every filter row");
@@ -258,8 +267,6 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   }
 
   // ---- epilogue ----
-  const float* bias_p = (flags & TFC_EP_BIAS) ? bias : nullptr;
-  const float osc = oscale ? *oscale : 1.f;                      // spectral norm: conv(x, W / sigma) = conv(x, W) / sigma
   constexpr bool STAGED = (ES == 2);                             // bf16: transpose through LDS, store whole 16-byte units
   constexpr int BN = 32 * NT * WN;
   constexpr int ROWP = BN * ES + 16;                             // LDS bytes per pixel row of the staged tile
@@ -267,7 +274,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   for (int nt = 0; nt < NT; ++nt) {
     const int n = (nb0 + nt) * 32 + r;
     const bool nok = n < d.Nout;
-    const float bv = (bias_p && nok) ? bias_p[n] : 0.f;
+    const float bv = bvs[nt];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
