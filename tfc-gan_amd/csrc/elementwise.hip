@@ -1126,7 +1126,10 @@ static inline dim3 act_grid(int npix, int C, int ue, int N) {
   const int cv = C / ue;
   const int ppb = 256 / cv;
   int nb = (npix + ppb - 1) / ppb;
-  int cap = 8192 / (N > 0 ? N : 1);
+#ifndef TFC_ACT_CAP
+#define TFC_ACT_CAP 4096                                           // ~16 grid-stride workgroups per CU; 8192 and more measured 0.4-0.6 % slower per step
+#endif
+  int cap = TFC_ACT_CAP / (N > 0 ? N : 1);
   if (cap < 1) cap = 1;
   if (nb > cap) nb = cap;
   return dim3(nb, N);
