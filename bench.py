@@ -7,8 +7,8 @@
 One process per GPU; each rank trains on its own 32 synthetic 256x256 thermal/visible pairs already resident in HBM
 (weak scaling), gradients are all-reduced over RCCL.  A "step" = the full generator step + discriminator step of
 TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py:545-638 (without LPIPS / temperature head).  Rank 0 prints ONE
-JSON line.  `roofline` is measured live with hipEvents around every launch of the dominant kernel (tfc_igemm_kernel, the
-halo-staged implicit-GEMM convolution) during the timed region; `cpu_baseline` times the CPU oracle (torch fp32 restatement
+JSON line.  `roofline` is measured live with hipEvents around the launches of the dominant kernel family (tfc_igemm_kernel, the
+halo-staged implicit-GEMM convolution) in every 4th step of the timed region; `cpu_baseline` times the CPU oracle (torch fp32 restatement
 of the same step) on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
@@ -97,7 +97,6 @@ def main():
     import torch
     import torch.distributed as dist
     import tfc_gan_amd as T
-    from oracle import tfcgan_oracle as O               # synthetic-input recipe only (inputs are data, not the measured path)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +123,7 @@ def main():
     G.apply(T.weights_init_normal)
     D.apply(T.weights_init_normal)
     ts = T.TrainStep(G, D, compute_dtype=torch.bfloat16)
-    A, B = O.synthetic_pairs(args.batch, seed=1234 + rank)
+    A, B = T.synthetic_pairs(args.batch, seed=1234 + rank)      # the product's own recipe: oracle/ is used by the checker legs only
     A, B = A.to(dev), B.to(dev)
 
     def barrier():

@@ -6,13 +6,12 @@ cat > /tmp/ab_step.py <<'PY'
 import sys, time, torch, os
 sys.path.insert(0, os.getcwd())
 import tfc_gan_amd as T
-from oracle import tfcgan_oracle as O
 dev = torch.device('cuda', 0)
 T.set_compute_dtype(torch.bfloat16); torch.manual_seed(42)
 G = T.GeneratorUNet((3,256,256)).to(dev); D = T.Discriminator1((3,256,256)).to(dev)
 G.apply(T.weights_init_normal); D.apply(T.weights_init_normal)
 ts = T.TrainStep(G, D, compute_dtype=torch.bfloat16)
-A, B = O.synthetic_pairs(32, seed=1234); A, B = A.to(dev), B.to(dev)
+A, B = T.synthetic_pairs(32, seed=1234); A, B = A.to(dev), B.to(dev)
 for _ in range(8): ts.step(A, B)
 best = 1e9
 for rep in range(3):

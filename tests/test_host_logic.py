@@ -187,3 +187,14 @@ def test_zero_arena_hands_out_zeroed_disjoint_views():
     a.begin()
     w = a.take((3, 5))
     assert w.data_ptr() == v1.data_ptr() and w.abs().sum() == 0
+
+
+def test_synthetic_input_recipe_matches_the_oracle():
+    """bench.py feeds the product's own synthetic_pairs (the timed path never imports oracle/); the recipe is the oracle's, bit for bit"""
+    from oracle import tfcgan_oracle as O
+    a, b = T.synthetic_pairs(2, seed=77)
+    oa, ob = O.synthetic_pairs(2, seed=77)
+    assert torch.equal(a, oa) and torch.equal(b, ob)
+    assert a.min() >= -1 and a.max() <= 1 and torch.equal(b[:, 0], b[:, 1]) and torch.equal(b[:, 0], b[:, 2])
+    t = T.synthetic_temperatures(2, seed=77)
+    assert t.shape == (2, 256, 256) and t.min() >= 24 and t.max() <= 38
