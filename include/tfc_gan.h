@@ -164,9 +164,13 @@ int tfc_adam_step(void* stream, float* p, const float* g, float* m, float* v, lo
 
 /* ---- measurement -------------------------------------------------------------------------------------------------- */
 /* When enabled every gather-GEMM / wgrad launch is bracketed by hipEvents on its own stream; tfc_prof_collect()
- * (call after synchronising) sums them per kernel class: 0 = tfc_igemm_kernel, 1 = tfc_wgrad_kernel. */
+ * (call after synchronising) sums them per kernel class: 0 = tfc_igemm_kernel family, 1 = tfc_wgrad family (+ slab reduce). */
 int tfc_prof_enable(int on);
 int tfc_prof_collect(int kclass, double* total_ms, double* algorithmic_flop, long long* launches);
+/* per-call detail of the records gathered on this thread since the last collect (kclass 2 = the wgrad finish pass): arrays of max_records entries,
+ * meta7 = {op, pass (0 fwd, 1 dgrad, 2 wgrad, 3 wgrad finish), N, H, W, Cin, Cout} per record; returns the number of records, < 0 on error.
+ * The profiling state is per THREAD: enable, launch and collect from the same thread. */
+int tfc_prof_records(int max_records, int* kclass, double* ms, double* algorithmic_flop, int* meta7);
 
 /* ---- test hooks (host side, no GPU): the table-driven gather model evaluated on the CPU with the SAME descriptors and
  * the SAME packed operand stream the kernels consume.  Never called by the product path. */

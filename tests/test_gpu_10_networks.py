@@ -234,3 +234,61 @@ def test_full_size_properties_batch32():
     assert abs(l.item() - 1.0) < 1e-6 and d.abs().max().item() == 0.0
     z, _, _ = T.patch_fft_loss(fake, fake)
     assert z.item() == 0.0
+
+
+def test_module_forward_sees_weights_updated_by_trainstep():
+    """the module's operand-stream cache is keyed on (data_ptr, _version); the raw-pointer Adam kernel moves neither.
+    G(x); ts.step(); G(x) must equal a FRESH module loaded from the same state_dict (P16:395 sample_images calls generator(real_A)
+    between optimiser steps), same for D."""
+    T.set_compute_dtype(torch.float32)
+    G = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=61).to(DEV).eval()
+    D = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=62).to(DEV).eval()
+    A, B = O.synthetic_pairs(1, seed=63)
+    A, B = A.to(DEV), B.to(DEV)
+    ts = T.TrainStep(G, D, compute_dtype=torch.float32)
+    with torch.no_grad():
+        y0, l0 = G(A), D(B, A)                               # packs the module's own operand streams
+    ts.step(A, B)
+    ts.step(A, B)
+    with torch.no_grad():
+        y1, l1 = G(A), D(B, A)
+    assert (y1 - y0).abs().max().item() > 1e-4               # the weights did move
+    G2 = T.GeneratorUNet((3, 256, 256)).to(DEV).eval()
+    G2.load_state_dict(G.state_dict())
+    D2 = T.Discriminator1((3, 256, 256)).to(DEV).eval()
+    D2.load_state_dict(D.state_dict())
+    with torch.no_grad():
+        y2, l2 = G2(A), D2(B, A)
+    assert (y1 - y2).abs().max().item() <= 1e-5, (y1 - y2).abs().max().item()
+    assert (l1 - l2).abs().max().item() <= 1e-5 * l2.abs().max().item()
+
+
+def test_trainstep_sees_load_state_dict():
+    """the reverse direction: load_state_dict AFTER TrainStep construction writes the flat buffer; the next step must re-pack its
+    operand streams (a resumed run, P16:447-450). Two engines stepping from the same loaded weights must agree."""
+    T.set_compute_dtype(torch.float32)
+    A, B = O.synthetic_pairs(1, seed=64)
+    A, B = A.to(DEV), B.to(DEV)
+    neg = list(range(1, 16)) + [0]
+    Gs = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=71)
+    Ds = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=72)
+    gsd = {k: v.clone() for k, v in Gs.state_dict().items()}
+    dsd = {k: v.clone() for k, v in Ds.state_dict().items()}
+    # engine 1: built on OTHER weights, then loaded
+    G1 = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=5).to(DEV).eval()
+    D1 = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=6).to(DEV).eval()
+    ts1 = T.TrainStep(G1, D1, compute_dtype=torch.float32)
+    ts1.step(A, B, neg_idx=neg)                               # streams packed from the seed-5/6 weights
+    G1.load_state_dict(gsd)
+    D1.load_state_dict(dsd)
+    # engine 2: built directly on the loaded weights
+    G2 = T.GeneratorUNet((3, 256, 256)); G2.load_state_dict(gsd); G2 = G2.to(DEV).eval()
+    D2 = T.Discriminator1((3, 256, 256)); D2.load_state_dict(dsd); D2 = D2.to(DEV).eval()
+    ts2 = T.TrainStep(G2, D2, compute_dtype=torch.float32)
+    ts1.step_no = 0
+    ts1.gm.zero_(); ts1.gv.zero_(); ts1.dm.zero_(); ts1.dv.zero_()
+    o1 = ts1.step(A, B, neg_idx=neg)
+    o2 = ts2.step(A, B, neg_idx=neg)
+    assert (o1["fake_B"] - o2["fake_B"]).abs().max().item() <= 1e-5
+    for k in ("loss_G", "loss_D"):
+        assert abs(float(o1[k]) - float(o2[k])) <= 1e-4 * max(1.0, abs(float(o2[k]))), k

@@ -2,6 +2,7 @@
 must end on the same parameters as one rank stepping all 4 images -- the all-reduced gradient mean equals the single-process
 batch mean up to fp32 summation order (reference semantics: nn.DataParallel gathers the batch and takes batch-mean losses, P16:444)."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -13,6 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "ddp_worker.py")
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_two_ranks_match_one_rank(tmp_path):
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -20,7 +29,7 @@ def test_two_ranks_match_one_rank(tmp_path):
     env.pop("RANK", None)
     subprocess.run([sys.executable, WORKER, one], check=True, env=env, timeout=300)           # child process, never an exec of this one
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                    "--master-port", "29541", WORKER, two], check=True, env=env, timeout=300)
+                    "--master-port", str(_free_port()), WORKER, two], check=True, env=env, timeout=300)
     a, b = torch.load(one, weights_only=True), torch.load(two, weights_only=True)
     # spectral-norm state evolves the same way on every rank (same weights, same iteration); its mat-vec reductions use fp32
     # atomics, so two runs agree to round-off, not bit for bit

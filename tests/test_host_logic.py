@@ -198,3 +198,42 @@ def test_synthetic_input_recipe_matches_the_oracle():
     assert a.min() >= -1 and a.max() <= 1 and torch.equal(b[:, 0], b[:, 1]) and torch.equal(b[:, 0], b[:, 2])
     t = T.synthetic_temperatures(2, seed=77)
     assert t.shape == (2, 256, 256) and t.min() >= 24 and t.max() <= 38
+
+
+def test_dataparallel_replica_is_refused_loudly():
+    """nn.DataParallel on several devices replicates the module (`_is_replica`): its copies hold no Parameters and would share the
+    operand-stream cache between threads, so forward raises and points at the one-process-per-GPU path (P16:444-445 replaced)"""
+    for mod, args in ((T.GeneratorUNet((3, 256, 256)), (torch.zeros(1, 3, 256, 256),)),
+                      (T.Discriminator1((3, 256, 256)), (torch.zeros(1, 3, 256, 256), torch.zeros(1, 3, 256, 256)))):
+        mod._is_replica = True
+        with pytest.raises(T.TfcError, match="one process per GPU|one\\s+process per GPU"):
+            mod(*args)
+
+
+def test_dropout_seed_streams_are_per_module():
+    """no process-global RNG counter: two modules draw independent, reproducible seed streams"""
+    from tfc_gan_amd import models
+    a, b = T.UNetDown(8, 8), T.UNetDown(8, 8)
+    a._drop_seed = b._drop_seed = 123
+    sa = [models._next_seed(a) for _ in range(3)]
+    sb = [models._next_seed(b) for _ in range(3)]
+    assert sa == sb and len(set(sa)) == 3
+    assert models._next_seed(a) != sb[0]
+
+
+def test_profiling_state_is_per_thread():
+    """tfc_prof_enable / tfc_debug_set_igemm_config act on the calling thread only (no process-global mutable state in the library)"""
+    import threading
+    lib = _lib.load()
+    assert lib.tfc_prof_enable(1) == 0
+    seen = {}
+
+    def other():
+        n = lib.tfc_prof_records(4, None, None, None, None)
+        seen["n"] = n
+        seen["rc"] = lib.tfc_debug_set_igemm_config(2)
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen == {"n": 0, "rc": 0}
+    assert lib.tfc_prof_enable(0) == 0

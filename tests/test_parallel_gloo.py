@@ -73,3 +73,45 @@ def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
         ref = g.reshape(-1)
         mine = got["avg"][s:s + ref.numel()]
         assert (mine - ref).abs().max().item() <= 1e-6 + 1e-4 * ref.abs().max().item(), k
+
+
+def _worker4(rank, world, port, out_path):
+    """four ranks, deliberately awkward bucket boundaries (5 MB buckets cut the 29.2 M-parameter buffer into ~20 uneven pieces; one
+    hook never fires, so finish() must flush its bucket), plus the logged-loss averaging collective"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from tfc_gan_amd import nets, parallel
+    G = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=90).eval()
+    named = {k: v for k, v in G.named_parameters()}
+    flat = parallel.FlatParams(named, nets.g_backward_order(), torch.device("cpu"))
+    red = parallel.BucketReducer(flat, bucket_bytes=5_000_000)
+    gen = torch.Generator().manual_seed(1000 + rank)
+    flat.grad.copy_(torch.randn(flat.numel, generator=gen))
+    mine = flat.grad.clone()
+    skipped = flat.order[3]
+    for k in flat.order:                                         # backward order; one gradient "forgets" its hook
+        if k != skipped:
+            red.ready(k)
+    scale = red.finish()
+    losses = torch.tensor([float(rank), 10.0 * rank, -1.0])
+    parallel.all_reduce_mean(losses)
+    gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, gathered, dst=0)
+    if rank == 0:
+        want = torch.stack(gathered).sum(0)
+        torch.save({"ok": bool(torch.allclose(flat.grad, want, rtol=1e-5, atol=1e-5)), "scale": scale, "losses": losses,
+                    "nbuckets": len(red.buckets), "sizes": [e - s for s, e, _ in red.buckets]}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_buckets_and_loss_mean(tmp_path):
+    world = 4
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker4, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=False)
+    assert got["ok"] and got["scale"] == 0.25
+    assert got["nbuckets"] >= 6 and len(set(got["sizes"])) > 2          # uneven pieces
+    assert torch.allclose(got["losses"], torch.tensor([1.5, 15.0, -1.0]))

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "tfc_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f]),
     "tfc_prof_enable": (_i, [_i]),
     "tfc_prof_collect": (_i, [_i, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_ll)]),
+    "tfc_prof_records": (_i, [_i, _c.POINTER(_i), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_i)]),
     "tfc_host_emulate_conv": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "tfc_debug_set_igemm_config": (_i, [_i]),
     "tfc_probe_mfma": (_i, [_vp, _vp]),

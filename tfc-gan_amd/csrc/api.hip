@@ -6,7 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
-#include <mutex>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "../../include/tfc_gan.h"
@@ -87,12 +87,18 @@ static inline int pad8(int c) { return (c + 7) / 8 * 8; }
 static inline int es_of(int dt) { return dt == TFC_DT_BF16 ? 2 : 4; }
 
 // ---- profiling: hipEvents around the two MFMA kernel classes ---------------------------------------------------
+// Per-THREAD state (the thread that enables profiling is the thread that launches and collects). Each record keeps the call's shape,
+// so tfc_prof_records() gives a per-layer table; TFC_LAUNCH_LOG=<file> (read once) additionally appends one line per conv-class call
+// "kclass op pass N H W Cin Cout flop nlaunch" -- the join key scripts/per_layer.py uses to split a rocprofv3 kernel trace by layer.
 namespace {
-struct ProfRec { hipEvent_t a, b; int kclass; double flop; };
-std::mutex g_prof_mu;
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof;
-std::vector<hipEvent_t> g_event_pool;
+struct ProfRec { hipEvent_t a, b; int kclass; double flop; int meta[7]; };
+thread_local bool g_prof_on = false;
+thread_local std::vector<ProfRec> g_prof;
+thread_local std::vector<hipEvent_t> g_event_pool;
+FILE* launch_log() {
+  static FILE* f = [] { const char* p = getenv("TFC_LAUNCH_LOG"); return (p && *p) ? fopen(p, "a") : (FILE*)nullptr; }();
+  return f;
+}
 hipEvent_t get_event() {
   if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
   hipEvent_t e;
@@ -103,24 +109,31 @@ struct ProfScope {
   bool on;
   hipStream_t st;
   ProfRec rec;
-  ProfScope(int kclass, double flop, hipStream_t s) : st(s) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
+  long long launches0;
+  ProfScope(int kclass, double flop, hipStream_t s, int op, int pass, int N, int H, int W, int Cin, int Cout) : st(s) {
     on = g_prof_on;
-    if (on) { rec.a = get_event(); rec.b = get_event(); rec.kclass = kclass; rec.flop = flop; hipEventRecord(rec.a, st); }
+    rec.kclass = kclass; rec.flop = flop;
+    const int m[7] = {op, pass, N, H, W, Cin, Cout};
+    memcpy(rec.meta, m, sizeof m);
+    launches0 = g_tfc_launch_count;
+    if (on) { rec.a = get_event(); rec.b = get_event(); hipEventRecord(rec.a, st); }
   }
   ~ProfScope() {
-    if (on) { hipEventRecord(rec.b, st); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(rec); }
+    if (on) { hipEventRecord(rec.b, st); g_prof.push_back(rec); }
+    if (FILE* f = launch_log()) {
+      fprintf(f, "%d %d %d %d %d %d %d %d %.0f %lld\n", rec.kclass, rec.meta[0], rec.meta[1], rec.meta[2], rec.meta[3], rec.meta[4], rec.meta[5],
+              rec.meta[6], rec.flop, g_tfc_launch_count - launches0);
+      fflush(f);
+    }
   }
 };
 }  // namespace
 
 extern "C" int tfc_prof_enable(int on) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
   return 0;
 }
 extern "C" int tfc_prof_collect(int kclass, double* total_ms, double* flop, long long* launches) {
-  std::lock_guard<std::mutex> lk(g_prof_mu);
   double ms = 0, fl = 0;
   long long n = 0;
   std::vector<ProfRec> keep;
@@ -138,6 +151,22 @@ extern "C" int tfc_prof_collect(int kclass, double* total_ms, double* flop, long
   if (flop) *flop = fl;
   if (launches) *launches = n;
   return 0;
+}
+// per-call detail of the records gathered so far on this thread (does not consume them): returns the number of records written
+extern "C" int tfc_prof_records(int max_records, int* kclass, double* ms, double* flop, int* meta7) {
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (n >= max_records) break;
+    float t = 0.f;
+    hipError_t e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hipfail(e, "tfc_prof_records (synchronise before collecting)");
+    if (kclass) kclass[n] = r.kclass;
+    if (ms) ms[n] = t;
+    if (flop) flop[n] = r.flop;
+    if (meta7) memcpy(meta7 + 7 * n, r.meta, sizeof r.meta);
+    ++n;
+  }
+  return n;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -365,7 +394,7 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
   int nph = num_phases(op, 0);
   const bool fold = (op == TFC_OP_CONVT || op == TFC_OP_UPCONV);   // equal-shaped phases: fold all four into the grid of one launch
   if (fold) nph = 1;
-  ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
+  ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream, op, 0, N, H, W, Cin, Cout);
   for (int ph = 0; ph < nph; ++ph) {
     TfcGather d;
     if (int e = build_desc(op, 0, ph, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, nullptr)) return e;
@@ -381,7 +410,7 @@ extern "C" int tfc_conv_dgrad_image(void* stream, int dt, const void* dy, int dy
   REQUIRE(dt == TFC_DT_BF16 && Cout == 64 && Cin >= 1 && nch >= 1 && nch <= 4 && nch <= Cin, "tfc_conv_dgrad_image: bf16, Cout == 64, nch <= min(4, Cin) only");
   REQUIRE(dy && w && dx_nchw && N > 0 && H > 4 && W > 4 && dy_pitch >= 64 && dy_pitch % 8 == 0, "bad args");
   if (int e = check_ptr16(dy, "dy")) return e;
-  ProfScope prof(0, 2.0 * N * (H - 1.0) * (W - 1.0) * nch * Cout * 16.0, (hipStream_t)stream);
+  ProfScope prof(0, 2.0 * N * (H - 1.0) * (W - 1.0) * nch * Cout * 16.0, (hipStream_t)stream, TFC_OP_CONV, 1, N, H, W, nch, Cout);
   CHECK_HIP(tfc_launch_dgrad_rows4(dy, dy_pitch, N, H, W, w, Cin, oscale, nch, dx_nchw, (hipStream_t)stream), "tfc_conv_dgrad_image");
   return 0;
 }
@@ -392,7 +421,7 @@ extern "C" int tfc_upconv_head_fwd(void* stream, int dt, const void* x, int x_pi
   REQUIRE(x && w && out_nchw && N > 0 && H > 1 && W > 1 && x_pitch >= 128 && x_pitch % 8 == 0, "bad args");
   if (int e = check_ptr16(x, "x")) return e;
   if (int e = check_ptr16(w, "w")) return e;
-  ProfScope prof(0, conv_flop(TFC_OP_UPCONV, N, H, W, Cin, Cout), (hipStream_t)stream);
+  ProfScope prof(0, conv_flop(TFC_OP_UPCONV, N, H, W, Cin, Cout), (hipStream_t)stream, TFC_OP_UPCONV, 0, N, H, W, Cin, Cout);
   CHECK_HIP(tfc_launch_upconv_head(x, x_pitch, N, H, W, w, bias, Cout, out_nchw, (hipStream_t)stream), "tfc_upconv_head_fwd");
   return 0;
 }
@@ -409,7 +438,7 @@ extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int 
   TfcGather d;
   if (int e = build_desc(op, 1, 0, N, H, W, Cin, Cout, dy_pitch, dx_pitch, &d, nullptr)) return e;
   if (int e = check_desc(d, dt)) return e;
-  ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream);
+  ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream, op, 1, N, H, W, Cin, Cout);
   CHECK_HIP(tfc_launch_igemm(dt, d, dy, packed, dx, nullptr, nullptr, nullptr, oscale, flags, (hipStream_t)stream), "tfc_conv_dgrad");
   return 0;
 }
@@ -485,7 +514,7 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
   hipStream_t st = (hipStream_t)stream;
   WeightMap wm{};                                                // the accumulator part of ws is all-zero on entry (caller zeroes it ONCE) and again on exit
   {
-    ProfScope prof(1, conv_flop(op, N, H, W, Cin, Cout), st);
+    ProfScope prof(1, conv_flop(op, N, H, W, Cin, Cout), st, op, 2, N, H, W, Cin, Cout);
     bool fused = false;
     if ((op == TFC_OP_CONVT || op == TFC_OP_UPCONV) && dt == TFC_DT_BF16) {   // all four sub-pixel phases in one launch
       TfcGather d0;
@@ -501,7 +530,10 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
       CHECK_HIP(tfc_launch_wgrad(dt, d, dy, x, (float*)((char*)ws + kWgradSlabBytes), ws, pad8(Cout), Cout, Cin, st), "tfc_conv_wgrad");
     }
   }
-  CHECK_HIP(tfc_launch_wgrad_finish((float*)((char*)ws + kWgradSlabBytes), dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
+  {
+    ProfScope prof(2, 0.0, st, op, 3, N, H, W, Cin, Cout);     // class 2: the finish pass (layout + re-zero), no algorithmic FLOP of its own
+    CHECK_HIP(tfc_launch_wgrad_finish((float*)((char*)ws + kWgradSlabBytes), dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
+  }
   return 0;
 }
 
@@ -679,7 +711,6 @@ extern "C" int tfc_adam_step(void* stream, float* p, const float* g, float* m, f
   CHECK_HIP(tfc_launch_adam(p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), gscale, (hipStream_t)stream), "tfc_adam_step");
   return 0;
 }
-extern int g_tfc_force_cfg;
 extern "C" int tfc_debug_set_igemm_config(int cfg) {
   REQUIRE(cfg >= -1 && cfg <= 3, "cfg must be -1 (heuristic), 0 (128x128), 1 (128x64) or 2 (128x32)");
   g_tfc_force_cfg = cfg;

@@ -748,7 +748,7 @@ hipError_t tfc_launch_dgrad_rows4(const void* dy, int dy_pitch, int N, int H, in
     grid_cap = (occ < 1 ? 1 : occ) * ncu;
   }
   const int nwork = N * ((H + 7) / 8) * ((W + 31) / 32);
-  hipLaunchKernelGGL(tfc_dgrad_rows4_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), lds, st, (const bf16_t*)dy, H - 1, W - 1, dy_pitch, w,
+  TFC_LAUNCH(tfc_dgrad_rows4_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), lds, st, (const bf16_t*)dy, H - 1, W - 1, dy_pitch, w,
                      Cin, oscale, NC, dx, H, W, N, nwork);
   return hipGetLastError();
 }
@@ -766,7 +766,7 @@ hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int 
     grid_cap = (occ < 1 ? 1 : occ) * ncu;
   }
   const int nwork = N * ((H + TFC_TILE_H - 1) / TFC_TILE_H) * ((W + TFC_TILE_W - 1) / TFC_TILE_W);
-  hipLaunchKernelGGL(tfc_upconv_head_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), lds, st, (const bf16_t*)x, H, W, x_pitch, w, bias,
+  TFC_LAUNCH(tfc_upconv_head_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), lds, st, (const bf16_t*)x, H, W, x_pitch, w, bias,
                      Cout, out, N, nwork);
   return hipGetLastError();
 }
@@ -1274,8 +1274,8 @@ tfc_pack_planned_kernel(const TfcPackJob* __restrict__ jobs, int njobs) {
   }
 }
 hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st) {
-  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_pack_planned_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
-  else hipLaunchKernelGGL((tfc_pack_planned_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
+  if (dt == TFC_DT_BF16) TFC_LAUNCH((tfc_pack_planned_kernel<bf16_t>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
+  else TFC_LAUNCH((tfc_pack_planned_kernel<float>), dim3(nblocks), dim3(256), 0, st, (const TfcPackJob*)plan_dev, njobs);
   return hipGetLastError();
 }
 
@@ -1547,7 +1547,7 @@ static hipError_t launch_pack_t(const TfcGather& d, const float* w, const float*
                                 long long sn, long long sc, hipStream_t st) {
   const int NB32 = tfc_nb32_padded(d.Nout);
   const int total = tfc_total_substeps(d, sizeof(T)) * NB32 * 64;
-  hipLaunchKernelGGL((tfc_pack_w_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, st, d, w, scale, (uint4*)wp, NB32,
+  TFC_LAUNCH((tfc_pack_w_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, st, d, w, scale, (uint4*)wp, NB32,
                      Nreal, Creal, sn, sc, total);
   return hipGetLastError();
 }
@@ -1601,7 +1601,7 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
   }
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1);
   const long long phase_wbytes = (long long)tfc_packed_bytes(d, ES);
-  hipLaunchKernelGGL((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
+  TFC_LAUNCH((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
                      (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes);
   return hipGetLastError();
 }
@@ -1621,7 +1621,8 @@ static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const voi
 // Tile-shape choice: 128 pixels x {128, 64, 32} channels. Wider N tiles reuse each A fragment more, but deep / up-path layers
 // have so few pixel tiles that a 128-wide tile leaves most of the 256 CUs idle -> narrow the tile until the grid has >= ~2
 // workgroups per CU (or the narrowest tile is reached).
-int g_tfc_force_cfg = -1;                                        // test hook (tfc_debug_set_igemm_config): -1 = heuristic
+thread_local int g_tfc_force_cfg = -1;                           // test hook (tfc_debug_set_igemm_config): -1 = heuristic; per thread
+thread_local long long g_tfc_launch_count = 0;
 
 template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
@@ -1641,7 +1642,7 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
         grid_cap = (occ < 1 ? 1 : occ) * ncu;
       }
       const int nwork = d.nimg * d.tiles_y * d.tiles_x;
-      hipLaunchKernelGGL(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
+      TFC_LAUNCH(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
                          (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork);
       return hipGetLastError();
     }
@@ -1675,6 +1676,9 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   int nsplit = 512 / (nbw * ncb);
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
+  // slab budget (api.hip reserves 512 workgroups x 128 KiB): a layer with more than 512 (n-block, c-block) pairs (e.g. 2048 x 1024) cannot keep
+  // one slab per workgroup -- such a layer flushes with fp32 atomics instead (slab = nullptr), it never writes past the region
+  if (slab && (long long)nbw * ncb * nsplit > 512) slab = nullptr;
   const int lds = (2 * 128 * 32 * ES + TFC_MAX_HH * TFC_MAX_HW * 32 * ES) * (ES == 2 ? 2 : 1);
   const dim3 grid(nbw * ncb * nsplit);
   if constexpr (ES == 2) {
@@ -1689,11 +1693,12 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
       int ns = 512 / (nbw * ncb2);
       if (ns > ntiles) ns = ntiles;
       if (ns < 1) ns = 1;
+      if (slab && (long long)nbw * ncb2 * ns > 512) slab = nullptr;   // same slab budget as below
       const int lds22 = 2 * (2 * 128 * 64 + 2 * d.plane[0].hh * d.plane[0].hw * 64);
-      hipLaunchKernelGGL((tfc_wgrad22_kernel<T>), dim3(nbw * ncb2 * ns), dim3(256), lds22, st, d, (const T*)dO, (const T*)in, dwacc, slab,
+      TFC_LAUNCH((tfc_wgrad22_kernel<T>), dim3(nbw * ncb2 * ns), dim3(256), lds22, st, d, (const T*)dO, (const T*)in, dwacc, slab,
                          Nn_pad, Nn_real, Cw_real, nbw, ncb2, ns);
       if (slab)
-        hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb2 * 4 * 4 * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 1, 4, ns, nbw * ncb2,
+        TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb2 * 4 * 4 * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 1, 4, ns, nbw * ncb2,
                            ncb2, Nn_real, Cw_real, -1);
       return hipGetLastError();
     }
@@ -1701,14 +1706,14 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   const int tpw = (d.plane[0].ntaps + 3) / 4;                    // taps per wave (tap t belongs to wave t % 4)
   bool raster = (ES == 2) && d.plane[0].ntaps == 16;
   for (int t = 0; t < 16 && raster; ++t) raster = d.plane[0].tap_dy[t] == (t >> 2) && d.plane[0].tap_dx[t] == (t & 3);
-#define TFC_WG(TPW_, R_) hipLaunchKernelGGL((tfc_wgrad_kernel<T, TPW_, R_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, slab, \
+#define TFC_WG(TPW_, R_) TFC_LAUNCH((tfc_wgrad_kernel<T, TPW_, R_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, slab, \
                                             Nn_pad, Nn_real, Cw_real, nbw, ncb, nsplit)
   int tw = 4;
   if (raster) TFC_WG(4, true);
   else if (tpw <= 1) { tw = 1; TFC_WG(1, false); } else if (tpw == 2) { tw = 2; TFC_WG(2, false); } else if (tpw == 3) { tw = 3; TFC_WG(3, false); } else TFC_WG(4, false);
 #undef TFC_WG
   if (slab)
-    hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * (tw * 2) * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 0, tw * 2, nsplit,
+    TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * (tw * 2) * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 0, tw * 2, nsplit,
                        nbw * ncb, ncb, Nn_real, Cw_real, -1);
   return hipGetLastError();
 }
@@ -1731,15 +1736,15 @@ bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW,
   const dim3 grid(nbw * ncb * nsplit);
   TfcPlane none{};
   if (up) {
-    hipLaunchKernelGGL(tfc_wgradT_kernel<true>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
+    TFC_LAUNCH(tfc_wgradT_kernel<true>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
                        Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
     for (int wv = 0; wv < 4; ++wv)                                // the phases overlap on the filter taps: one reduce pass per phase, in order
-      hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 3, T, nsplit,
+      TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 3, T, nsplit,
                          nbw * ncb, ncb, Cout, Cin, wv);
   } else {
-    hipLaunchKernelGGL(tfc_wgradT_kernel<false>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
+    TFC_LAUNCH(tfc_wgradT_kernel<false>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
                        Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
-    hipLaunchKernelGGL(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 2, T, nsplit,
+    TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 2, T, nsplit,
                        nbw * ncb, ncb, Cout, Cin, -1);
   }
   *err = hipGetLastError();
@@ -1754,7 +1759,7 @@ hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const vo
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
                                    int accumulate, hipStream_t st) {
   const int total = Nn * Cw;                                      // one thread per (n, c): all 16 taps
-  hipLaunchKernelGGL(tfc_wgrad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, acc, grad, Nn, Cw, sn, sc,
+  TFC_LAUNCH(tfc_wgrad_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, acc, grad, Nn, Cw, sn, sc,
                      accumulate, total);
   return hipGetLastError();
 }

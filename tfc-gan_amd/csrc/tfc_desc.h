@@ -78,3 +78,11 @@ struct ActParams {
   unsigned seed;
   float drop_scale;
 };
+
+#ifdef __cplusplus
+// Host-side hooks shared by the translation units of the library. All per-THREAD (the reference calls forward from several Python
+// threads; nothing in the library is process-global mutable state).
+extern thread_local int g_tfc_force_cfg;          // test hook (tfc_debug_set_igemm_config): -1 = heuristic tile choice
+extern thread_local long long g_tfc_launch_count; // kernel launches issued by the conv-class launchers on this thread (profiling join key)
+#define TFC_LAUNCH(...) do { ++g_tfc_launch_count; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#endif

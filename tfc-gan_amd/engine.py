@@ -56,7 +56,19 @@ class TrainStep:
         self.D.set_params(self.dflat.views, self.dbufs)
         self.G.repack()
         self.D.repack()
+        self._pversions = self._param_versions()
         self.last = {}
+
+    def _param_versions(self):
+        """autograd version counters of the module parameters: they move when the CALLER writes the weights (load_state_dict,
+        optimizer of its own, .apply(init)); the raw-pointer Adam kernel of this class does not touch them."""
+        return tuple(p._version for m in (self.G_mod, self.D_mod) for p in m.parameters())
+
+    def _invalidate_module_cores(self):
+        """the modules' own forward (sample_images P16:391-416, eval) caches operand streams keyed on (data_ptr, _version); the Adam
+        kernel changes neither, so bump the modules' weight generation after every update"""
+        self.G_mod._weights_gen += 1
+        self.D_mod._weights_gen += 1
 
     def _gl(self, like):
         return ops.new_act(like.N, like.H, like.W, 8, self.dt, self.dev, zero=True)
@@ -71,6 +83,12 @@ class TrainStep:
             neg_idx = parallel.shared_neg_idx(t, self.seed)
         drop_seed = (self.seed * 7919 + t * 104729 + parallel.rank() * 1299709) & 0x3FFFFFF
         train = self.G_mod.training
+        pv = self._param_versions()
+        if pv != self._pversions:                                 # weights written from outside since the last step (load_state_dict): re-pack
+            self.G.repack()
+            self.D.repack()
+            self._invalidate_module_cores()
+            self._pversions = pv
         ops.arena_begin(self.dev)                                 # one fill for all the small zero-initialised buffers of this step
         # ---------------- generator step ----------------
         fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
@@ -85,7 +103,8 @@ class TrainStep:
             loss_fft, loss_amp, loss_pha = global_fft_loss(fake, real_B)
         g_fake = self.D.backward(dctx_f, g_pf, grads=None, need_input_grad=True)
         ops.axpby(g_fake, g_fake, g_trip, 1.0, 1.0)
-        if extra_loss_G is not None:                              # optional pluggable term (LPIPS / temperature): returns (loss, dfake)
+        extra = None
+        if extra_loss_G is not None:                              # optional pluggable term (LPIPS, P16:598): returns (loss, dfake), already weighted
             extra, g_extra = extra_loss_G(fake, real_B)
             ops.axpby(g_fake, g_fake, g_extra, 1.0, 1.0)
         self.G.backward(gctx, g_fake, self.gflat.grad_views, hook=self.g_reduce.ready)
@@ -103,7 +122,10 @@ class TrainStep:
         ops.adam_step(self.dflat.data, self.dflat.grad, self.dm, self.dv, self.lr, self.b1, self.b2, self.eps, t, dscale)
         self.D.repack()
         ops.arena_end(self.dev)
-        loss_g = self.lambda_gan * loss_gan + loss_trip + self.lambda_fft * loss_fft
+        self._invalidate_module_cores()
+        loss_g = self.lambda_gan * loss_gan + self.lambda_trip * loss_trip + self.lambda_fft * loss_fft
+        if extra is not None:
+            loss_g = loss_g + extra.reshape(loss_g.shape).to(loss_g.dtype)
         loss_temp = None
         if T_B is not None:
             loss_temp = temperature_triplet_loss(fake, T_B, B_tf if B_tf is not None else real_B)
@@ -113,6 +135,14 @@ class TrainStep:
                      "fake_B": fake}
         if loss_temp is not None:
             self.last["loss_temp_g"] = loss_temp
+        if extra is not None:
+            self.last["loss_extra_g"] = extra.reshape(())
+        if parallel.world_size() > 1:                             # every logged loss is a batch mean: mean over ranks = the global-batch value
+            keys = [k for k in self.last if k != "fake_B"]
+            packed = torch.stack([self.last[k].reshape(()).float() for k in keys])
+            parallel.all_reduce_mean(packed)
+            for i, k in enumerate(keys):
+                self.last[k] = packed[i]
         return self.last
 
     # algorithmic work of one step per image: conv / convT MACs x 2

@@ -2,8 +2,10 @@
 
 Same names, constructor signatures, child names (`down1..down6, up1..up5, final`, `.model` nn.Sequential indices) and
 therefore the same state_dict keys / shapes as TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py:102-211, so the reference's
-train / test scripts (`.apply(weights_init_normal)`, `nn.DataParallel`, `load_state_dict`, test_TFCGAN_16Patches.py's
-`load_clean_state`) work unchanged.  The stock torch modules inside `.model` only HOLD parameters and buffers; `forward`
+train / test scripts (`.apply(weights_init_normal)`, `load_state_dict`, `.cuda()`, test_TFCGAN_16Patches.py's
+`load_clean_state`) work unchanged.  `nn.DataParallel` (P16:444-445) is accepted as a wrapper on ONE device only: its
+multi-device replicas hold no Parameters and would share one operand-stream cache across threads, so a replica's forward
+raises TfcError pointing at the one-process-per-GPU path (TrainStep + parallel.py), which is how this engine scales.  The stock torch modules inside `.model` only HOLD parameters and buffers; `forward`
 never calls them -- it runs the gather-GEMM / fused kernels through torch.autograd.Function wrappers.
 
 There is no `ContrastiveLoss` / `Discriminator` class in the reference script; both names are exported as documented
@@ -77,12 +79,20 @@ class _BlurFn(torch.autograd.Function):
         return _to_nchw(dx, g), None, None
 
 
-_SEED_COUNTER = [0x5EED]
+def _next_seed(module):
+    """per-MODULE dropout seed stream (an LCG on an attribute of the module: no process-global mutable state)"""
+    s = (getattr(module, "_drop_seed", 0x5EED ^ (id(module) & 0xFFFF)) * 1103515245 + 12345) & 0x7FFFFFFF
+    object.__setattr__(module, "_drop_seed", s)
+    return s
 
 
-def _next_seed():
-    _SEED_COUNTER[0] = (_SEED_COUNTER[0] * 1103515245 + 12345) & 0x7FFFFFFF
-    return _SEED_COUNTER[0]
+def _refuse_replica(module):
+    """nn.DataParallel's replicate() marks its per-device copies `_is_replica`; they carry plain tensors instead of Parameters and share
+    this module's operand-stream cache between threads -- refuse loudly instead of computing with a mix of weights"""
+    if getattr(module, "_is_replica", False):
+        raise ops._lib.TfcError(f"{type(module).__name__} was called inside a multi-device nn.DataParallel replica. This engine scales as one "
+                                "process per GPU: launch with torch.distributed.run, build the modules on cuda:LOCAL_RANK and use "
+                                "tfc_gan_amd.TrainStep (bucketed RCCL all-reduce, tfc_gan_amd.parallel) instead of nn.DataParallel (INTEGRATION.md).")
 
 
 class _DownFn(torch.autograd.Function):
@@ -183,7 +193,7 @@ class UNetDown(nn.Module):
 
     def forward(self, x):
         p = self.dropout if self.training else 0.0
-        return _DownFn.apply(x, self.model[0].weight, self.normalize, p, _next_seed(), ops.dt_of(get_compute_dtype()))
+        return _DownFn.apply(x, self.model[0].weight, self.normalize, p, _next_seed(self), ops.dt_of(get_compute_dtype()))
 
 
 class UNetUp(nn.Module):
@@ -198,7 +208,7 @@ class UNetUp(nn.Module):
 
     def forward(self, x, skip_input):
         p = self.dropout if self.training else 0.0
-        y = _UpFn.apply(x, self.model[0].weight, p, _next_seed(), ops.dt_of(get_compute_dtype()))
+        y = _UpFn.apply(x, self.model[0].weight, p, _next_seed(self), ops.dt_of(get_compute_dtype()))
         return torch.cat((y, skip_input.to(y.dtype)), 1)
 
 
@@ -242,6 +252,7 @@ class GeneratorUNet(nn.Module):
         self.compute_dtype = None            # None -> package default
         self._core = None
         self._core_key = None
+        self._weights_gen = 0                # bumped by TrainStep after each raw-pointer Adam update (neither data_ptr nor _version moves)
 
     def named_core_params(self):
         sd = dict(self.named_parameters())
@@ -250,7 +261,7 @@ class GeneratorUNet(nn.Module):
     def _core_for(self, device):
         dt = ops.dt_of(self.compute_dtype or get_compute_dtype())
         params = self.named_core_params()
-        key = (dt, str(device)) + tuple((p.data_ptr(), p._version) for p in params.values())
+        key = (dt, str(device), self._weights_gen) + tuple((p.data_ptr(), p._version) for p in params.values())
         if self._core is None or self._core.dt != dt:
             self._core = nets.GeneratorCore(dt, self.channels)
         if key != self._core_key:
@@ -263,8 +274,9 @@ class GeneratorUNet(nn.Module):
         return self._core
 
     def forward(self, x):
+        _refuse_replica(self)
         params = self.named_core_params()
-        return _GeneratorFn.apply(self, x, _next_seed(), *params.values())
+        return _GeneratorFn.apply(self, x, _next_seed(self), *params.values())
 
 
 class _DiscriminatorFn(torch.autograd.Function):
@@ -311,6 +323,7 @@ class Discriminator1(nn.Module):
         self.compute_dtype = None
         self._core = None
         self._core_key = None
+        self._weights_gen = 0
 
     def named_core_params(self):
         sd = dict(self.named_parameters())
@@ -328,7 +341,7 @@ class Discriminator1(nn.Module):
     def _core_for(self, device):
         dt = ops.dt_of(self.compute_dtype or get_compute_dtype())
         params, bufs = self.named_core_params(), self.named_core_buffers()
-        key = (dt, str(device)) + tuple((p.data_ptr(), p._version) for p in params.values()) + tuple(b.data_ptr() for b in bufs.values())
+        key = (dt, str(device), self._weights_gen) + tuple((p.data_ptr(), p._version) for p in params.values()) + tuple(b.data_ptr() for b in bufs.values())
         if self._core is None or self._core.dt != dt:
             self._core = nets.DiscriminatorCore(dt, self.channels)
         if key != self._core_key:
@@ -341,6 +354,7 @@ class Discriminator1(nn.Module):
         return self._core
 
     def forward(self, img_A, img_B):
+        _refuse_replica(self)
         params = self.named_core_params()
         return _DiscriminatorFn.apply(self, img_A, img_B, *params.values())
 

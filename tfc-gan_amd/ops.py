@@ -417,6 +417,19 @@ def prof_enable(on):
     check(lib().tfc_prof_enable(1 if on else 0), "tfc_prof_enable")
 
 
+def prof_records(max_records=4096):
+    """per-call records since the last collect: list of dicts {kclass, ms, flop, op, pass, N, H, W, Cin, Cout} (synchronise first)"""
+    kc = (ctypes.c_int * max_records)()
+    ms = (ctypes.c_double * max_records)()
+    fl = (ctypes.c_double * max_records)()
+    meta = (ctypes.c_int * (7 * max_records))()
+    n = lib().tfc_prof_records(max_records, kc, ms, fl, meta)
+    if n < 0:
+        check(n, "tfc_prof_records")
+    keys = ("op", "pass", "N", "H", "W", "Cin", "Cout")
+    return [dict(kclass=kc[i], ms=ms[i], flop=fl[i], **{k: meta[7 * i + j] for j, k in enumerate(keys)}) for i in range(n)]
+
+
 def prof_collect(kclass):
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
     check(lib().tfc_prof_collect(kclass, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "tfc_prof_collect")

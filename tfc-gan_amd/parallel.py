@@ -107,6 +107,15 @@ class BucketReducer:
         return 1.0 / ws
 
 
+def all_reduce_mean(t, group=None):
+    """in-place mean over the ranks of a small tensor (the logged losses: one collective of ~10 floats per step)"""
+    ws = world_size()
+    if ws > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t /= ws
+    return t
+
+
 def broadcast_flat(flat: FlatParams, src=0, group=None):
     if world_size() > 1:
         dist.broadcast(flat.data, src=src, group=group)
