@@ -289,6 +289,6 @@ def test_trainstep_sees_load_state_dict():
     ts1.gm.zero_(); ts1.gv.zero_(); ts1.dm.zero_(); ts1.dv.zero_()
     o1 = ts1.step(A, B, neg_idx=neg)
     o2 = ts2.step(A, B, neg_idx=neg)
-    assert (o1["fake_B"] - o2["fake_B"]).abs().max().item() <= 1e-5
+    assert (o1["fake_B"] - o2["fake_B"]).abs().max().item() <= 1e-4      # fp32 statistics atomics: summation order differs run to run
     for k in ("loss_G", "loss_D"):
         assert abs(float(o1[k]) - float(o2[k])) <= 1e-4 * max(1.0, abs(float(o2[k]))), k

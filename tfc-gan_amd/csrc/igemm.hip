@@ -71,8 +71,22 @@ template <> struct TapPat<6> : TapPatRC<3, 3, false> {};   // upsample-conv: eve
 #ifndef TFC_BD
 #define TFC_BD 4
 #endif
+// Diagnostic build only (-DTFC_STAMP, scripts/stamp_igemm.py): s_memtime stamps of the kernel's phases go to `out_nchw` (a buffer of their
+// own, never an output element); no stamp executes in the shipped library.
+#ifdef TFC_STAMP
+#define TFC_STAMP_AT(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0 && out_nchw && !(flags & TFC_EP_TANH_NCHW)) reinterpret_cast<unsigned long long*>(out_nchw)[((size_t)blockIdx.x * 4 + wave) * 16 + (slot)] = t_; } while (0)
+#else
+#define TFC_STAMP_AT(slot) do { } while (0)
+#endif
 #ifndef TFC_MINW
 #define TFC_MINW 3
+#endif
+#ifndef TFC_BD2
+#define TFC_BD2 4          // persistent kernel: weight-ring depth (k-substeps); 3 x 3 tap pattern (18 k-substeps per stage): 2, 3 or 6
+#endif
+#ifndef TFC_BD2_PAT6
+#define TFC_BD2_PAT6 2
 #endif
 template <typename T, int MT, int NT, int WM, int WN, int PAT>
 __global__ void __launch_bounds__(256, TFC_MINW)
@@ -92,6 +106,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, r = lane & 31;
+  TFC_STAMP_AT(0);
 
   const int PB = PAT ? 64 : tfc_pb(d.Cin_pad, ES);
   const int UPP = PB >> 4;
@@ -183,6 +198,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
     halo_load(0);
     halo_store(smem);
     __syncthreads();
+    TFC_STAMP_AT(1);
     int gs = 0;
     for (int st = 0; st < nst; ++st) {
       const bool more = (st + 1) < nst;
@@ -267,6 +283,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
   }
 
   // ---- epilogue ----
+  TFC_STAMP_AT(2);
   constexpr bool STAGED = (ES == 2);                             // bf16: transpose through LDS, store whole 16-byte units
   constexpr int BN = 32 * NT * WN;
   constexpr int ROWP = BN * ES + 16;                             // LDS bytes per pixel row of the staged tile
@@ -311,8 +328,10 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
       }
     }
   }
+  TFC_STAMP_AT(3);
   if (STAGED && !(flags & TFC_EP_TANH_NCHW)) {
     __syncthreads();
+    TFC_STAMP_AT(4);
     constexpr int UPR = BN / 8;                                  // 16-byte units per pixel row of the tile
     const int nbase = nb_blk * BN;
 #pragma unroll 2
@@ -349,6 +368,487 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
       }
     }
   }
+#ifdef TFC_STAMP
+  TFC_STAMP_AT(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TFC_STAMP_AT(6);
+  if (lane == 0 && out_nchw && !(flags & TFC_EP_TANH_NCHW)) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    reinterpret_cast<unsigned long long*>(out_nchw)[((size_t)blockIdx.x * 4 + wave) * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tfc_igemm2_kernel -- the bf16 production form of the gather GEMM above: PERSISTENT workgroups, two per CU.
+//
+// What the s_memtime stamps of the one-tile-per-workgroup kernel showed at the shape of down2 (profiles/r02_stamps_igemm_v1.md): a wave spends
+// 16 % of its life in the prologue (first halo + weight fragments: a cold round trip per tile), 19 % transposing its accumulators through
+// LDS with 64 two-byte ds_write per lane (all twelve waves of a CU contend for the LDS store path), and inside the K loop it already runs at
+// the MFMA-bound rate; the 768-slot grid also quantises badly (5.33 / 2.67 / 1.33 rounds for down2 / down3 / down4).  Hence:
+//   * grid = 2 workgroups per CU (512): a workgroup walks work items  b, b + G, ...  (8 / 4 / 2 whole rounds for the three big shapes);
+//   * the stream of (tile, stage) is ONE software pipeline: the halo of the next tile's first chunk is requested at the start of the current
+//     tile's last stage and stored behind it, the weight ring runs on into the next tile's stream during the last filter row, and both are
+//     issued BEFORE the epilogue's stores (vmcnt retires in order) -- a tile never starts cold;
+//   * operands are SWAPPED in the MFMA (A = weight fragment, B = pixel fragment): the accumulator then holds  row = channel, column (lane) =
+//     pixel, i.e. four consecutive CHANNELS of one pixel per four registers.  Two v_cvt_pk + one v_permlane32_swap pair turn them into whole
+//     16-byte units (8 channels) and the tile reaches LDS with 8 ds_write_b128 per lane instead of 64 ds_write_b16 (conflict-free: rows in
+//     MFMA order, row pitch = 4 banks mod 32);
+//   * bias lives in LDS per tile (the channel now varies with the register, not with the lane); InstanceNorm statistics are taken in the
+//     store pass from the bf16 values actually stored (the values the normaliser will read), reduced over the lanes that share a unit column.
+// Weight fragments still stream from L2 per wave (lane-linear 1-KiB loads): cfg "no redundant B" measured +3 % only, the prologue/epilogue
+// were the loss.
+// ---------------------------------------------------------------------------------------------------
+template <int OFF> __device__ __forceinline__ void lds_rd(u32x4_t& dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = B .. E-1 (immediates of the inline-asm statements must be constants)
+template <int B, int E, typename F> __device__ __forceinline__ void tfc_static_for(F&& f) {
+  if constexpr (B < E) { f(std::integral_constant<int, B>{}); tfc_static_for<B + 1, E>(f); }
+}
+struct Tile2 {
+  int img, a0, b0, phy, phx, nb_blk;
+  const unsigned char* wbase;                                    // this tile's weight stream (phase, n-block), wave part excluded
+};
+
+template <int MT, int NT, int WM, int WN, int PAT>
+__global__ void __launch_bounds__(256, 2)
+tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* out,
+                  const float* __restrict__ bias, float* stats, float* dbg, const float* __restrict__ oscale,
+                  int flags, int NB32, int nblkN, int buf_bytes, long long phase_wbytes, int nwork, unsigned* qctr, int npool, int stagger_cycles) {
+  static_assert(WM * WN == 4 && WM * MT == 4, "4 waves, 128-pixel tile");
+  static_assert(PAT != 0, "compile-time tap patterns only");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef bf16_t T;
+  constexpr int P = TFC_LDS_P;
+  constexpr int NSR = TapPat<PAT>::COLS * 2;
+  constexpr int ROWS = TapPat<PAT>::ROWS;
+  constexpr int BD = (PAT == 6) ? TFC_BD2_PAT6 : TFC_BD2;           // weight-ring depth in k-substeps
+  static_assert((ROWS * NSR) % BD == 0, "register ring must realign every stage");
+  constexpr int BN = 32 * NT * WN;
+  constexpr int ROWP = BN * 2 + 16;                              // staged tile: bytes per pixel row (pitch = 4 banks mod 32)
+  constexpr int UPR = BN / 8;                                    // 16-byte units per pixel row
+  float* out_nchw = dbg;                                         // TFC_STAMP_AT writes here in the diagnostic build
+  (void)out_nchw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, r = lane & 31;
+  const int G = gridDim.x;
+  TFC_STAMP_AT(0);
+#ifdef TFC_STAMP
+#define TFC_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+  unsigned long long tk0 = 0, tk1 = 0, acc_main = 0, acc_ep1 = 0, acc_bar = 0, acc_store = 0, ntile = 0, ts0 = 0, ts1 = 0, acc_sync = 0, tq0 = 0, tq1 = 0, tq2 = 0, acc_h = 0, acc_f = 0;
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime(), mt_begin = __builtin_amdgcn_s_memtime();
+#else
+#define TFC_NOW(v) do { } while (0)
+#endif
+
+  const int nchunks = (d.Cin_pad * 2) / 64;
+  const int nst = nchunks * d.nplanes;
+  unsigned char* stage = smem + 2 * buf_bytes;
+  float* sstat = reinterpret_cast<float*>(stage + 128 * ROWP);   // [2][BN][2] statistics partials of the current / the previous tile (zero when unused)
+  int* snext = reinterpret_cast<int*>(sstat + 4 * BN);           // 4 words: work items published by thread 0
+  float* sbias = reinterpret_cast<float*>(snext + 4);            // bias of EVERY output channel of the layer (nblkN * BN floats), loaded once
+
+  const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * 80 + h * 16;
+  const unsigned lanepart = (unsigned)((wn * NT) * 64 + lane) * 16u;
+  const size_t wstep_b = (size_t)NB32 * 1024;
+  const float osc = oscale ? *oscale : 1.f;
+
+  auto decode = [&](int bid, Tile2& t) {                          // bid: logical work item (n-block fastest, then tile, image, phase)
+    t.nb_blk = bid % nblkN;
+    int tile = bid / nblkN;
+    const int txb = tile % d.tiles_x; tile /= d.tiles_x;
+    const int tyb = tile % d.tiles_y; tile /= d.tiles_y;
+    t.img = tile % d.nimg;
+    const int phase = tile / d.nimg;
+    t.phy = phase >> 1; t.phx = phase & 1;
+    t.a0 = tyb * TFC_TILE_H; t.b0 = txb * TFC_TILE_W;
+    t.wbase = reinterpret_cast<const unsigned char*>(wp) + (size_t)phase * (size_t)phase_wbytes + (size_t)(t.nb_blk * WN * NT) * 1024;
+  };
+
+  // ---- memory operations of the K loop: inline asm with hand-counted waits.  hipcc (ROCm 7.2) schedules the compiler-visible form badly
+  //      (the ISA it emitted: s_waitcnt vmcnt(0) in front of every conditional halo load -- five drains of the weight ring per stage -- and
+  //      each ds_read_b128 sunk to its MFMA and followed by lgkmcnt(0)); an asm load is invisible to its s_waitcnt bookkeeping, so EVERY
+  //      wait below is counted by hand and the counts are STATIC: the four halo loads and the NT weight loads of a k-substep are always
+  //      issued (clamped addresses instead of branches).  vmcnt retires in order:  wait vmcnt(N) guarantees a load once at most N younger
+  //      vector-memory operations exist; assuming FEWER younger operations than really were issued only waits longer, never too short.
+  u32x4_t hv[4];
+  int hoff[4];                                                   // LDS byte offset of this thread's halo unit i (-1: none)
+  int hyS[4], hxS[4], hrel[4];                                   // tile-invariant source geometry: row / column step and element offset of the unit
+  unsigned hvalid = 0;                                           // bit i: halo unit i is inside the source image (else: zero padding)
+  {
+    // every plane of a descriptor has the same halo extent (api.hip: build_desc), so (hy, hx) of a unit -- two integer divisions -- are
+    // computed ONCE per launch; a stage only adds its plane's origin (the per-stage divisions and 64-bit multiplies this replaces cost a lone
+    // wave ~2,000 cycles per stage: half as much again as the stage's 128 MFMAs)
+    const int hw0 = d.plane[0].hw, nunits = d.plane[0].hh * d.plane[0].hw * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int pix = idx >> 2, g = idx & 3;
+      const int hy = pix / hw0, hx = pix - hy * hw0;
+      hoff[i] = idx < nunits ? (hy * P + hx) * 80 + g * 16 : -1;
+      hyS[i] = hy * d.SS; hxS[i] = hx * d.SS;
+      hrel[i] = (hyS[i] * d.IW + hxS[i]) * d.in_pitch + g * 8;
+    }
+  }
+  auto halo_load = [&](const Tile2& t, int st) {
+    const int pl = st & (d.nplanes - 1), cc = d.nplanes == 4 ? (st >> 2) : st;      // nplanes is 1 or 4
+    const TfcPlane& pd = d.plane[pl];
+    const int Y0 = (t.a0 + pd.dy0 + t.phy * d.ph_d0) * d.SS + pd.py, X0 = (t.b0 + pd.dx0 + t.phx * d.ph_d0) * d.SS + pd.px;
+    const bf16_t* base = in + ((long long)t.img * d.IH * d.IW + (long long)Y0 * d.IW + X0) * d.in_pitch + cc * 32;   // wave-uniform
+    hvalid = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = hoff[i] >= 0 && (unsigned)(Y0 + hyS[i]) < (unsigned)d.IH && (unsigned)(X0 + hxS[i]) < (unsigned)d.IW;
+      const bf16_t* src = ok ? base + hrel[i] : in;
+      hvalid |= ok ? (1u << i) : 0u;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hv[i]) : "v"(src) : "memory");
+    }
+  };
+  auto halo_store = [&](unsigned char* buf) {                    // caller has waited for the four loads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("" : "+v"(hv[i]));
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+      const u32x4_t v = (hvalid >> i) & 1u ? hv[i] : z;
+      if (hoff[i] >= 0) *reinterpret_cast<u32x4_t*>(buf + hoff[i]) = v;
+    }
+  };
+  auto loadB = [&](const unsigned char* p, u32x4_t (&b)[NT]) {    // p: this lane's address of the fragment of n-block 0
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nt == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[0]) : "v"(p) : "memory");
+      if (nt == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(b[1]) : "v"(p) : "memory");
+      if (nt == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(b[2]) : "v"(p) : "memory");
+      if (nt == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(b[3]) : "v"(p) : "memory");
+    }
+  };
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(unsigned char, smem);   // LDS byte address of the dynamic region
+
+  // store pass of the epilogue: thread -> (unit column su, staged rows rho = tid / UPR + kk * 256 / UPR); element offset of (row, unit) inside a tile's
+  // output window is tile-invariant
+  constexpr int NSK = (128 * UPR) / 256;
+  const int su = tid % UPR;
+  int srel[NSK];
+#pragma unroll
+  for (int kk = 0; kk < NSK; ++kk) {
+    const int rho = tid / UPR + kk * (256 / UPR);
+    const int rr = rho & 31;
+    const int ty = 2 * (rho >> 5) + (rr & 1), tx = rr >> 1;
+    srel[kk] = (ty * d.OS * d.OW + tx * d.OS) * d.out_pitch + su * 8;
+  }
+
+  // ---- work distribution: one small pool of work items per PAIR of workgroups ----
+  // Equal static shares do not finish together: the two workgroups of a CU run equal tiles, but the waves dispatched first win every
+  // arbitration (priority, then age) -- measured at the shape of down2: the first-dispatched 256 workgroups needed 99 us for their 8 tiles, the
+  // second 256 needed 134 us and spent the last quarter alone on half-empty CUs.  Work items are therefore PULLED.  Pool p = blockIdx % NP
+  // (NP = number of CUs; workgroups b and b + NP are observed to share a CU -- speed only, any placement is correct) owns the items
+  // j * NP + r(p), j = 0, 1, ...  (r = XCD-aware bijection: the pools of one XCD hold neighbouring tiles of a round).  A workgroup's first
+  // item is static (j = blockIdx / NP); every further one is  j = (workgroups of the pool) + atomicAdd(counter[p], 1)  -- one returning
+  // device-scope atomic per tile on a 64-byte line shared by TWO workgroups (a counter shared by the 64 workgroups of an XCD took 3-4 us per
+  // fetch), issued one tile ahead behind the K loop and read where the pipeline is drained anyway.  qctr[p * 16] = counter, [p * 16 + 1] =
+  // finished workgroups of the pool; the pool's last finisher re-zeroes both.
+  const int NP = G < npool ? G : npool;
+  const int pool = blockIdx.x % NP;
+  const int pool_wgs = (G - pool + NP - 1) / NP;                  // workgroups that pull from this pool
+  const int pool_r = tfc_xcd_remap(pool, NP);
+  unsigned* qc = qctr + (size_t)pool * 16;
+  auto q_item = [&](int j) { const long long L = (long long)j * NP + pool_r; return L < (long long)nwork ? (int)L : -1; };
+  int w = q_item(blockIdx.x / NP), w_next;
+  {
+    if (tid == 0) snext[0] = w < 0 ? -1 : q_item(pool_wgs + (int)atomicAdd(qc, 1u));
+    __syncthreads();
+    w_next = __builtin_amdgcn_readfirstlane(snext[0]);            // wave-uniform BY CONSTRUCTION; say so, or every tile parameter lives in VGPRs
+    __syncthreads();
+  }
+  auto q_finish = [&]() {                                         // every workgroup, once, after its last fetch has returned
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(qc + 1, 1u) == (unsigned)pool_wgs - 1u) { atomicExch(qc, 0u); atomicExch(qc + 1, 0u); }
+    }
+  };
+  if (w < 0) { q_finish(); return; }
+  Tile2 cur, nxt;
+  decode(w, cur);
+  nxt = cur;
+  // Stagger: the two workgroups of a pool run equal tiles; started together they reach their epilogues (VALU / LDS / stores, no MFMA) together and
+  // the matrix pipe idles twice per tile period.  The second workgroup of a pool starts half a period late, so that one's epilogue runs under
+  // the other's K loop for the rest of the launch (placement-dependent like the pool pairing: speed only).
+  if (stagger_cycles > 0 && (int)blockIdx.x >= NP) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger_cycles) __builtin_amdgcn_s_sleep(32);
+  }
+  u32x4_t br[BD][NT];
+#pragma unroll
+  for (int i = 0; i < BD; ++i) loadB(cur.wbase + lanepart + (size_t)i * wstep_b, br[i]);
+  const unsigned char* bptr = cur.wbase + lanepart + (size_t)BD * wstep_b;   // next fragment to request (per lane)
+  if (flags & TFC_EP_BIAS)
+    for (int n = tid; n < nblkN * BN; n += 256) sbias[n] = n < d.Nout ? bias[n] : 0.f;
+  for (int n = tid; n < 4 * BN; n += 256) sstat[n] = 0.f;
+  halo_load(cur, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  halo_store(smem);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  TFC_STAMP_AT(1);
+  int sc = 0;                                                    // running stage counter: halo buffer parity across tiles
+
+  // InstanceNorm statistics leave the workgroup one tile LATE: memory-side float atomics stay on the wave's vmcnt for ~3,000 cycles and vmcnt
+  // retires in order, so atomics issued at the end of a tile stall the first counted wait of the next tile's K loop for that long (measured:
+  // +6,000 cycles per tile). The tile's sums therefore wait in LDS (two parities) and wave 0 adds the PREVIOUS tile's sums to memory right
+  // after the K loop, where ~3,000 cycles of register-only epilogue work follow before the pipeline is drained anyway.
+  float* stat_prev = nullptr;
+  int stat_lim = 0, tcount = 0;
+  auto stat_flush = [&]() {                                       // wave 0; every workgroup barrier since the previous tile's LDS adds is behind us
+    if (stat_prev && wave == 0) {
+      float* sp = sstat + ((tcount - 1) & 1) * 2 * BN;
+#pragma unroll
+      for (int i = lane; i < 2 * BN; i += 64) {
+        const float v = sp[i];
+        sp[i] = 0.f;
+        if (i < stat_lim) atomicAdd(stat_prev + i, v);
+      }
+    }
+  };
+  for (;;) {
+    const bool has_next = w_next >= 0;
+    if (has_next) decode(w_next, nxt);
+
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+
+    TFC_NOW(tk0);
+    for (int st = 0; st < nst; ++st) {
+      const bool last = (st + 1) == nst;
+      const bool more = !last || has_next;
+      // always FOUR loads (static vmcnt counts): the next stage's halo, or -- nothing follows -- a harmless re-read that is never stored
+#ifdef TFC_STAMP
+      TFC_NOW(tq0);
+#endif
+      halo_load((last && has_next) ? nxt : cur, last ? 0 : st + 1);
+#ifdef TFC_STAMP
+      TFC_NOW(tq1); acc_h += tq1 - tq0;
+#endif
+      const unsigned abase = lds0 + (sc & 1) * buf_bytes + laneBase;
+      constexpr int Q = ROWS * NSR;                               // k-substeps of one stage, one straight-line pipeline
+      u32x4_t a[2][MT];
+      tfc_static_for<0, MT>([&](auto mic) {
+        constexpr int mi = decltype(mic)::value;
+        lds_rd<(TapPat<PAT>::dy(0) * P + TapPat<PAT>::dx(0)) * 80 + mi * (2 * P * 80)>(a[0][mi], abase);
+      });
+#ifdef TFC_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TFC_NOW(tq2); acc_f += tq2 - tq1;
+#endif
+      tfc_static_for<0, Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        // operands of this k-substep.  A(q) was requested during k-substep q - 1 (nothing younger on the LDS queue); of the weight loads
+        // (BD - 1) * NT are younger than B(q), plus -- during the first BD k-substeps of a stage -- the four halo loads issued at its start
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(a[q & 1][mi]));
+        if constexpr (q < BD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * NT + 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * NT) : "memory");
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[q % BD][nt]));
+        if constexpr (q + BD == Q) { if (last && has_next) bptr = nxt.wbase + lanepart; }
+        // One wave issues in order: memory instructions bunched behind the last MFMA of a k-substep all land in ONE 32-cycle MFMA gap and overrun
+        // it (measured: ~60 idle matrix-pipe cycles per k-substep for a wave alone on its SIMD).  They are therefore dealt out over the gaps,
+        // at most two per gap, and the order is pinned with sched_barrier (the MFMAs are builtins: nothing else keeps hipcc from re-bunching):
+        //   after MFMA i (n-block-major order): A fragment i of the NEXT k-substep (other register set); after the last MFMA of n-block nt:
+        //   the weight fragment of n-block nt BD k-substeps ahead (its register is free from here on)
+        tfc_static_for<0, MT * NT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, nt = i / MT, mi = i % MT;
+          acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, br[q % BD][nt]),      // swapped operands: rows =
+                                                                __builtin_bit_cast(bf16x8_t, a[q & 1][mi]), acc[mi][nt], 0, 0, 0);   // channels, lanes = pixels
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef TFC_ABL_NOA
+          if constexpr (q + 1 < Q) {
+            constexpr int r1 = (q + 1) / NSR, s1 = (q + 1) % NSR;
+            constexpr int off = (TapPat<PAT>::dy(r1) * P + TapPat<PAT>::dx(s1 >> 1)) * 80 + (s1 & 1) * 32;
+            constexpr int per = (MT + MT * NT - 1) / (MT * NT);    // A reads per gap (1 unless there are fewer MFMAs than A fragments)
+            tfc_static_for<i * per, (i * per + per < MT ? i * per + per : MT)>([&](auto mc) {
+              constexpr int m2 = decltype(mc)::value;
+              lds_rd<off + m2 * (2 * P * 80)>(a[(q + 1) & 1][m2], abase);
+            });
+          }
+#endif
+#ifndef TFC_ABL_NOB
+          if constexpr (mi == MT - 1) {
+            if constexpr (nt == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(br[q % BD][0]) : "v"(bptr) : "memory");
+            if constexpr (nt == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(br[q % BD][1]) : "v"(bptr) : "memory");
+            if constexpr (nt == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(br[q % BD][2]) : "v"(bptr) : "memory");
+            if constexpr (nt == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(br[q % BD][3]) : "v"(bptr) : "memory");
+          }
+#endif
+          if constexpr (i == MT * NT - 1) bptr += wstep_b;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      // the halo loads are older than every weight load of this stage: with at most BD * NT vector-memory operations left they have landed
+#ifdef TFC_STAMP
+      TFC_NOW(ts0);
+#endif
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BD * NT) : "memory");
+      if (more) halo_store(smem + ((sc + 1) & 1) * buf_bytes);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#ifdef TFC_STAMP
+      TFC_NOW(ts1); acc_sync += ts1 - ts0;
+#endif
+      ++sc;
+    }
+
+    // the item after next: vmcnt retires in order, so a returning atomic issued at the top of the tile would stall the first counted wait of the
+    // K loop for its whole round trip (~1 us under load); issued HERE it has the register phase of the epilogue (~1.5 us) to come back before
+    // the drain below
+    unsigned qv = 0;
+    if (tid == 0 && has_next) qv = atomicAdd(qc, 1u);
+    if (flags & TFC_EP_STATS) stat_flush();
+    // ---- epilogue: accumulators (channel rows x pixel lanes) -> 16-byte units -> staged tile in LDS ----
+    TFC_STAMP_AT(2);
+#ifdef TFC_STAMP
+    TFC_NOW(tk1); acc_main += tk1 - tk0; tk0 = tk1; ++ntile;
+#endif
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float4 bq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        bq[q] = (flags & TFC_EP_BIAS) ? *reinterpret_cast<const float4*>(sbias + cur.nb_blk * BN + (wn * NT + nt) * 32 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v0 = acc[mi][nt][4 * q + 0] * osc + bq[q].x, v1 = acc[mi][nt][4 * q + 1] * osc + bq[q].y;
+          float v2 = acc[mi][nt][4 * q + 2] * osc + bq[q].z, v3 = acc[mi][nt][4 * q + 3] * osc + bq[q].w;
+          if (flags & TFC_EP_LEAKY) { v0 = fmaxf(v0, 0.2f * v0); v1 = fmaxf(v1, 0.2f * v1); v2 = fmaxf(v2, 0.2f * v2); v3 = fmaxf(v3, 0.2f * v3); }
+          pk[q][0] = pack_bf16x2(v0, v1);
+          pk[q][1] = pack_bf16x2(v2, v3);
+        }
+        const int rho = (wm * MT + mi) * 32 + r;                  // LDS row = MFMA column order (pixel: ty = 2*ms + (r & 1), tx = r >> 1)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          // lanes < 32 hold channels 8q+0..3 (q = 2pr) and want 8q+4..7 from their partner lane + 32, which in turn wants this lane's group 2pr+1
+          auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+          const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          *reinterpret_cast<uint4*>(stage + rho * ROWP + ((wn * NT + nt) * 32 + pr * 16 + h * 8) * 2) = o;
+        }
+      }
+    }
+    TFC_STAMP_AT(3);
+#ifdef TFC_STAMP
+    TFC_NOW(tk1); acc_ep1 += tk1 - tk0; tk0 = tk1;
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the next tile's first weight fragments (requested ~2.5k cycles ago) land BEFORE the stores below
+#pragma unroll
+    for (int i = 0; i < BD; ++i)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[i][nt]));
+    if (tid == 0) snext[0] = has_next ? q_item(pool_wgs + (int)qv) : -1;
+    __syncthreads();
+    const int w_next2 = __builtin_amdgcn_readfirstlane(snext[0]);
+    TFC_STAMP_AT(4);
+#ifdef TFC_STAMP
+    TFC_NOW(tk1); acc_bar += tk1 - tk0; tk0 = tk1;
+#endif
+    {
+      const int n0 = cur.nb_blk * BN + su * 8;
+      const int ylim = d.GH - cur.a0, xlim = d.GW - cur.b0;
+      // wave-uniform part of the output address of this tile (the per-thread part srel[k] is tile-invariant)
+      bf16_t* obase = out + ((long long)(cur.img * d.OH + cur.a0 * d.OS + d.OOY + cur.phy * d.ph_oo) * d.OW + cur.b0 * d.OS + d.OOX + cur.phx * d.ph_oo) * d.out_pitch +
+                      cur.nb_blk * BN;
+      float s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < NSK; ++kk) {
+        const int rho = tid / UPR + kk * (256 / UPR);
+        const int rr = rho & 31;
+        const int ty = 2 * (rho >> 5) + (rr & 1), tx = rr >> 1;
+        if (ty < ylim && tx < xlim && n0 < d.Nout) {
+          T* po = obase + srel[kk];
+          uint4 v = *reinterpret_cast<const uint4*>(stage + rho * ROWP + su * 16);
+          if (flags & (TFC_EP_ACCUM | TFC_EP_STATS)) {
+            float f[8];
+            unpack16<bf16_t>(v, f);
+            if (flags & TFC_EP_ACCUM) {
+              float g[8];
+              unpack16<bf16_t>(*reinterpret_cast<const uint4*>(po), g);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] += g[e];
+              v = pack16<bf16_t>(f);
+              if (flags & TFC_EP_STATS) unpack16<bf16_t>(v, f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
+          }
+          store_stream16(po, v);
+        }
+      }
+      if (flags & TFC_EP_STATS) {
+        // lanes with equal (lane % UPR) hold partial sums of the same 8 channels: butterfly over them, then the four waves meet in LDS (float
+        // atomics on 2 * BN words), and ONE wave adds the tile's 2 * BN sums to memory as whole 256-byte runs of stats[img][n][2] -- 16 global
+        // atomics per lane at a 64-byte lane stride (the first version) ran 6x slower than the whole convolution
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int o = 32; o >= UPR; o >>= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        if (lane < UPR) {
+          float* sp = sstat + (tcount & 1) * 2 * BN;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { atomicAdd(&sp[(su * 8 + e) * 2], s1[e]); atomicAdd(&sp[(su * 8 + e) * 2 + 1], s2[e]); }
+        }
+        stat_prev = stats + ((size_t)cur.img * d.Nout + cur.nb_blk * BN) * 2;
+        stat_lim = 2 * (d.Nout - cur.nb_blk * BN);                // floats of this n-block that exist
+      }
+    }
+    ++tcount;
+    TFC_STAMP_AT(5);
+#ifdef TFC_STAMP
+    TFC_NOW(tk1); acc_store += tk1 - tk0;
+#endif
+    if (!has_next) break;
+    cur = nxt;
+    w = w_next;
+    w_next = w_next2;
+  }
+  if (flags & TFC_EP_STATS) {                                     // the last tile's sums
+    __syncthreads();
+    stat_flush();
+  }
+  q_finish();
+#ifdef TFC_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TFC_STAMP_AT(6);
+  if (lane == 0 && dbg) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(dbg) + ((size_t)blockIdx.x * 4 + wave) * 16;
+    o[2] = acc_main; o[3] = acc_ep1; o[4] = acc_bar; o[5] = acc_store; o[7] = ntile; o[1] = acc_sync; o[8] = acc_h; o[9] = acc_f;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[6] = ((unsigned long long)xcc << 32) | hwid;
+    o[0] = __builtin_amdgcn_s_memtime() - mt_begin;               // wave lifetime in shader cycles ...
+    o[6] = __builtin_amdgcn_s_memrealtime() - rt_begin;            // ... and in 100 MHz ticks (replaces the placement word)
+  }
+#endif
+#undef TFC_NOW
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1606,9 +2106,84 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
   return hipGetLastError();
 }
 
+// persistent bf16 kernel: 2 workgroups per CU pull work items (tile x n-block x phase) from per-XCD counters
+#define TFC_QSETS 8
+#define TFC_QPOOLS 512                                           // pools per set (>= CUs of the device), one 64-byte line each
+__device__ unsigned g_tfc_queue_ctr[TFC_QSETS * TFC_QPOOLS * 16];   // zero-initialised with the code object; every launch leaves its set zeroed
+static unsigned* tfc_queue_counters() {
+  static thread_local unsigned* p = nullptr;
+  static thread_local int dev_of = -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (!p || dev != dev_of) {
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tfc_queue_ctr)) != hipSuccess) return nullptr;
+    p = (unsigned*)sym; dev_of = dev;
+  }
+  return p;
+}
+static int tfc_num_cus() {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  return ncu;
+}
+template <int MT, int NT, int WM, int WN, int PAT>
+static hipError_t launch_igemm2_pat(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
+                                    float* stats, float* dbg, const float* oscale, int flags, hipStream_t st) {
+  const int NB32 = tfc_nb32_padded(d.Nout);
+  const int per_blk = NT * WN;
+  const int nblkN = (tfc_nb32(d.Nout) + per_blk - 1) / per_blk;
+  int maxhh = 0;
+  for (int pl = 0; pl < d.nplanes; ++pl) maxhh = d.plane[pl].hh > maxhh ? d.plane[pl].hh : maxhh;
+  const int buf_bytes = maxhh * TFC_LDS_P * 80;
+  constexpr int BN = 32 * NT * WN;
+  const int lds = 2 * buf_bytes + 128 * (BN * 2 + 16) + 4 * BN * 4 + 16 + nblkN * BN * 4;   // halo x 2 | staged tile | statistics | queue words | bias table
+  const int nwork = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1) * nblkN;
+  const int ncu = tfc_num_cus();
+  static const int wg_per_cu = [] { const char* e = getenv("TFC_WG_PER_CU"); return e ? atoi(e) : 2; }();   // diagnostic knob
+  const int cap = wg_per_cu * ncu;
+  const long long phase_wbytes = (long long)tfc_packed_bytes(d, 2);
+  // work-pool counters: TFC_QSETS sets used round-robin (a set is all zero whenever no launch is using it: each pool's last workgroup re-zeroes its
+  // line), so launches that overlap on different streams do not share a set
+  static thread_local unsigned seq = 0;
+  unsigned* qbase = tfc_queue_counters();
+  if (!qbase) return hipErrorInvalidSymbol;
+  unsigned* qctr = qbase + (size_t)(seq++ % TFC_QSETS) * TFC_QPOOLS * 16;
+  const int npool = ncu < TFC_QPOOLS ? ncu : TFC_QPOOLS;
+  const int nst = (d.Cin_pad * 2 / 64) * d.nplanes;
+  const int mfma_cycles = nst * TapPat<PAT>::ROWS * TapPat<PAT>::COLS * 2 * MT * NT * 32;   // one wave's matrix-pipe time per tile
+  static const int stagger_env = [] { const char* e = getenv("TFC_STAGGER"); return e ? atoi(e) : -1; }();
+  int stagger = (nwork >= 3 * cap) ? mfma_cycles + 5000 : 0;
+  if (stagger_env >= 0) stagger = stagger_env == 0 ? 0 : (stagger_env == 1 ? mfma_cycles + 5000 : stagger_env);
+  const int lds_q = lds;
+  TFC_LAUNCH((tfc_igemm2_kernel<MT, NT, WM, WN, PAT>), dim3(nwork < cap ? nwork : cap), dim3(256), lds_q, st, d, (const bf16_t*)in, (const uint4*)wp,
+             (bf16_t*)out, bias, stats, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork, qctr, npool, stagger);
+  return hipGetLastError();
+}
+template <int MT, int NT, int WM, int WN>
+static hipError_t launch_igemm2_cfg(int pat, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
+                                    float* stats, float* dbg, const float* oscale, int flags, hipStream_t st) {
+  switch (pat) {
+    case 1: return launch_igemm2_pat<MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
+    case 2: return launch_igemm2_pat<MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
+    case 3: return launch_igemm2_pat<MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
+    default: return launch_igemm2_pat<MT, NT, WM, WN, 6>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
+  }
+}
+
 template <typename T, int MT, int NT, int WM, int WN>
 static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
                                    float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    // bf16, compile-time tap pattern, whole 16-byte output units, NHWC output: the persistent kernel (test hook: config | 16 = one tile per workgroup)
+    const int pat = match_pattern(d, 2);
+    static const bool legacy_env = [] { const char* e = getenv("TFC_LEGACY_IGEMM"); return e && atoi(e) != 0; }();   // A/B knob for profiling
+    if (pat != 0 && d.Nout % 8 == 0 && !(flags & TFC_EP_TANH_NCHW) && !(g_tfc_force_cfg >= 16) && !legacy_env)
+      return launch_igemm2_cfg<MT, NT, WM, WN>(pat, d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  }
   switch (match_pattern(d, sizeof(T))) {
     case 1: return launch_igemm_pat<T, MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
     case 2: return launch_igemm_pat<T, MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
@@ -1628,6 +2203,7 @@ template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
                                  float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   const int nb = tfc_nb32(d.Nout);
+  const int fcfg = g_tfc_force_cfg < 0 ? -1 : (g_tfc_force_cfg & 15);     // bit 4 of the test hook selects the one-tile-per-workgroup kernel
   if constexpr (sizeof(T) == 2) {
     // first-layer shape (8 padded input channels, 4 x 4 raster taps, <= 64 output channels, bias / scale epilogue only)
     if (g_tfc_force_cfg < 0 && d.Cin_pad == 8 && d.nplanes == 1 && d.ph_n <= 1 && d.SS == 1 && d.OS == 1 && plane_pattern(d.plane[0]) == 1 &&
@@ -1647,10 +2223,10 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
       return hipGetLastError();
     }
   }
-  if (g_tfc_force_cfg == 3 && nb >= 4) return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if (g_tfc_force_cfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if ((g_tfc_force_cfg == 0 || g_tfc_force_cfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if (g_tfc_force_cfg >= 0) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (fcfg == 3 && nb >= 4) return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (fcfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if ((fcfg == 0 || fcfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (fcfg >= 0 && fcfg != 15) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
   const int target = 512;
   if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
@@ -1682,7 +2258,7 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   const int lds = (2 * 128 * 32 * ES + TFC_MAX_HH * TFC_MAX_HW * 32 * ES) * (ES == 2 ? 2 : 1);
   const dim3 grid(nbw * ncb * nsplit);
   if constexpr (ES == 2) {
-    bool t22 = d.plane[0].ntaps == 4 && g_tfc_force_cfg != 2;
+    bool t22 = d.plane[0].ntaps == 4 && (g_tfc_force_cfg < 0 || (g_tfc_force_cfg & 15) != 2);
     int seen = 0;
     for (int t = 0; t < 4 && t22; ++t) {
       t22 = (unsigned)d.plane[0].tap_dy[t] < 2u && (unsigned)d.plane[0].tap_dx[t] < 2u;
@@ -1720,7 +2296,7 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
 // transposed convolution / upsample conv, bf16: all four phases in one launch; false = not applicable (caller falls back to per-phase launches)
 bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
                                    int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err) {
-  if (g_tfc_force_cfg == 2) return false;                         // tests: keep the per-phase kernels reachable
+  if (g_tfc_force_cfg >= 0 && (g_tfc_force_cfg & 15) == 2) return false;   // tests: keep the per-phase kernels reachable
   const int Nn_pad = (Cout + 7) / 8 * 8;
   const int nbw = (Nn_pad + 31) / 32, ncb = (Cin_pad + 31) / 32;
   const int ntiles = N * ((IH + TFC_TILE_H - 1) / TFC_TILE_H) * ((IW + TFC_TILE_W - 1) / TFC_TILE_W);
