@@ -418,7 +418,7 @@ template <int MT, int NT, int WM, int WN, int PAT>
 __global__ void __launch_bounds__(256, 2)
 tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* out,
                   const float* __restrict__ bias, float* stats, float* dbg, const float* __restrict__ oscale,
-                  int flags, int NB32, int nblkN, int buf_bytes, long long phase_wbytes, int nwork, unsigned* qctr, int npool, int stagger_cycles) {
+                  int flags, int NB32, int nblkN, int buf_bytes, long long phase_wbytes, int nwork) {
   static_assert(WM * WN == 4 && WM * MT == 4, "4 waves, 128-pixel tile");
   static_assert(PAT != 0, "compile-time tap patterns only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -453,8 +453,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   const int nst = nchunks * d.nplanes;
   unsigned char* stage = smem + 2 * buf_bytes;
   float* sstat = reinterpret_cast<float*>(stage + 128 * ROWP);   // [2][BN][2] statistics partials of the current / the previous tile (zero when unused)
-  int* snext = reinterpret_cast<int*>(sstat + 4 * BN);           // 4 words: work items published by thread 0
-  float* sbias = reinterpret_cast<float*>(snext + 4);            // bias of EVERY output channel of the layer (nblkN * BN floats), loaded once
+  float* sbias = sstat + 4 * BN;                                 // bias of EVERY output channel of the layer (nblkN * BN floats), loaded once
 
   const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * 80 + h * 16;
   const unsigned lanepart = (unsigned)((wn * NT) * 64 + lane) * 16u;
@@ -545,46 +544,20 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
     srel[kk] = (ty * d.OS * d.OW + tx * d.OS) * d.out_pitch + su * 8;
   }
 
-  // ---- work distribution: one small pool of work items per PAIR of workgroups ----
-  // Equal static shares do not finish together: the two workgroups of a CU run equal tiles, but the waves dispatched first win every
-  // arbitration (priority, then age) -- measured at the shape of down2: the first-dispatched 256 workgroups needed 99 us for their 8 tiles, the
-  // second 256 needed 134 us and spent the last quarter alone on half-empty CUs.  Work items are therefore PULLED.  Pool p = blockIdx % NP
-  // (NP = number of CUs; workgroups b and b + NP are observed to share a CU -- speed only, any placement is correct) owns the items
-  // j * NP + r(p), j = 0, 1, ...  (r = XCD-aware bijection: the pools of one XCD hold neighbouring tiles of a round).  A workgroup's first
-  // item is static (j = blockIdx / NP); every further one is  j = (workgroups of the pool) + atomicAdd(counter[p], 1)  -- one returning
-  // device-scope atomic per tile on a 64-byte line shared by TWO workgroups (a counter shared by the 64 workgroups of an XCD took 3-4 us per
-  // fetch), issued one tile ahead behind the K loop and read where the pipeline is drained anyway.  qctr[p * 16] = counter, [p * 16 + 1] =
-  // finished workgroups of the pool; the pool's last finisher re-zeroes both.
-  const int NP = G < npool ? G : npool;
-  const int pool = blockIdx.x % NP;
-  const int pool_wgs = (G - pool + NP - 1) / NP;                  // workgroups that pull from this pool
-  const int pool_r = tfc_xcd_remap(pool, NP);
-  unsigned* qc = qctr + (size_t)pool * 16;
-  auto q_item = [&](int j) { const long long L = (long long)j * NP + pool_r; return L < (long long)nwork ? (int)L : -1; };
-  int w = q_item(blockIdx.x / NP), w_next;
-  {
-    if (tid == 0) snext[0] = w < 0 ? -1 : q_item(pool_wgs + (int)atomicAdd(qc, 1u));
-    __syncthreads();
-    w_next = __builtin_amdgcn_readfirstlane(snext[0]);            // wave-uniform BY CONSTRUCTION; say so, or every tile parameter lives in VGPRs
-    __syncthreads();
-  }
-  auto q_finish = [&]() {                                         // every workgroup, once, after its last fetch has returned
-    if (tid == 0) {
-      __threadfence();
-      if (atomicAdd(qc + 1, 1u) == (unsigned)pool_wgs - 1u) { atomicExch(qc, 0u); atomicExch(qc + 1, 0u); }
-    }
+  // ---- work distribution: static round-robin, work item of round k = k * G + r(blockIdx) (r: XCD-aware bijection, the workgroups of one XCD
+  //      hold neighbouring tiles of a round).  Measured alternatives at the three big shapes, all within +-2 % of this one and therefore not
+  //      kept: pulling items from per-CU-pair counters (balances the pair -- the first-dispatched workgroup of a CU wins every arbitration and
+  //      finishes its equal share ~25 % earlier -- but each returning atomic sits on the in-order vmcnt queue), a half-period start stagger of the
+  //      second workgroup, s_setprio schemes.
+  auto item = [&](int k) {
+    const int cnt = (nwork - k * G) < G ? (nwork - k * G) : G;   // the last round may be partial
+    return (int)blockIdx.x < cnt ? k * G + tfc_xcd_remap(blockIdx.x, cnt) : -1;
   };
-  if (w < 0) { q_finish(); return; }
+  int round = 0;
+  int w = item(0), w_next = item(1);
   Tile2 cur, nxt;
   decode(w, cur);
   nxt = cur;
-  // Stagger: the two workgroups of a pool run equal tiles; started together they reach their epilogues (VALU / LDS / stores, no MFMA) together and
-  // the matrix pipe idles twice per tile period.  The second workgroup of a pool starts half a period late, so that one's epilogue runs under
-  // the other's K loop for the rest of the launch (placement-dependent like the pool pairing: speed only).
-  if (stagger_cycles > 0 && (int)blockIdx.x >= NP) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger_cycles) __builtin_amdgcn_s_sleep(32);
-  }
   u32x4_t br[BD][NT];
 #pragma unroll
   for (int i = 0; i < BD; ++i) loadB(cur.wbase + lanepart + (size_t)i * wstep_b, br[i]);
@@ -712,11 +685,6 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
       ++sc;
     }
 
-    // the item after next: vmcnt retires in order, so a returning atomic issued at the top of the tile would stall the first counted wait of the
-    // K loop for its whole round trip (~1 us under load); issued HERE it has the register phase of the epilogue (~1.5 us) to come back before
-    // the drain below
-    unsigned qv = 0;
-    if (tid == 0 && has_next) qv = atomicAdd(qc, 1u);
     if (flags & TFC_EP_STATS) stat_flush();
     // ---- epilogue: accumulators (channel rows x pixel lanes) -> 16-byte units -> staged tile in LDS ----
     TFC_STAMP_AT(2);
@@ -760,9 +728,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
     for (int i = 0; i < BD; ++i)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[i][nt]));
-    if (tid == 0) snext[0] = has_next ? q_item(pool_wgs + (int)qv) : -1;
     __syncthreads();
-    const int w_next2 = __builtin_amdgcn_readfirstlane(snext[0]);
     TFC_STAMP_AT(4);
 #ifdef TFC_STAMP
     TFC_NOW(tk1); acc_bar += tk1 - tk0; tk0 = tk1;
@@ -826,14 +792,14 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 #endif
     if (!has_next) break;
     cur = nxt;
+    ++round;
     w = w_next;
-    w_next = w_next2;
+    w_next = item(round + 1);
   }
   if (flags & TFC_EP_STATS) {                                     // the last tile's sums
     __syncthreads();
     stat_flush();
   }
-  q_finish();
 #ifdef TFC_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TFC_STAMP_AT(6);
@@ -2106,22 +2072,7 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
   return hipGetLastError();
 }
 
-// persistent bf16 kernel: 2 workgroups per CU pull work items (tile x n-block x phase) from per-XCD counters
-#define TFC_QSETS 8
-#define TFC_QPOOLS 512                                           // pools per set (>= CUs of the device), one 64-byte line each
-__device__ unsigned g_tfc_queue_ctr[TFC_QSETS * TFC_QPOOLS * 16];   // zero-initialised with the code object; every launch leaves its set zeroed
-static unsigned* tfc_queue_counters() {
-  static thread_local unsigned* p = nullptr;
-  static thread_local int dev_of = -1;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (!p || dev != dev_of) {
-    void* sym = nullptr;
-    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_tfc_queue_ctr)) != hipSuccess) return nullptr;
-    p = (unsigned*)sym; dev_of = dev;
-  }
-  return p;
-}
+// persistent bf16 kernel: 2 workgroups per CU walk the work items (tile x n-block x phase)
 static int tfc_num_cus() {
   static int ncu = 0;
   if (!ncu) {
@@ -2140,27 +2091,21 @@ static hipError_t launch_igemm2_pat(const TfcGather& d, const void* in, const vo
   for (int pl = 0; pl < d.nplanes; ++pl) maxhh = d.plane[pl].hh > maxhh ? d.plane[pl].hh : maxhh;
   const int buf_bytes = maxhh * TFC_LDS_P * 80;
   constexpr int BN = 32 * NT * WN;
-  const int lds = 2 * buf_bytes + 128 * (BN * 2 + 16) + 4 * BN * 4 + 16 + nblkN * BN * 4;   // halo x 2 | staged tile | statistics | queue words | bias table
+  const int lds = 2 * buf_bytes + 128 * (BN * 2 + 16) + 4 * BN * 4 + nblkN * BN * 4;   // halo x 2 | staged tile | statistics x 2 | bias table
   const int nwork = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1) * nblkN;
-  const int ncu = tfc_num_cus();
-  static const int wg_per_cu = [] { const char* e = getenv("TFC_WG_PER_CU"); return e ? atoi(e) : 2; }();   // diagnostic knob
-  const int cap = wg_per_cu * ncu;
+  // resident workgroups per CU of THIS instantiation (2 for the 128-channel tile: 77 KB of LDS, ~195 VGPRs; 3 for the narrower tiles); a persistent
+  // grid never depends on co-residency for correctness (no inter-workgroup waits), so the occupancy query only sizes the grid
+  static thread_local int occ_cache = 0, occ_lds = -1;
+  if (!occ_cache || occ_lds != lds) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_igemm2_kernel<MT, NT, WM, WN, PAT>, 256, (size_t)lds) != hipSuccess || occ < 1) occ = 2;
+    occ_cache = occ > 3 ? 3 : occ;
+    occ_lds = lds;
+  }
+  const int cap = occ_cache * tfc_num_cus();
   const long long phase_wbytes = (long long)tfc_packed_bytes(d, 2);
-  // work-pool counters: TFC_QSETS sets used round-robin (a set is all zero whenever no launch is using it: each pool's last workgroup re-zeroes its
-  // line), so launches that overlap on different streams do not share a set
-  static thread_local unsigned seq = 0;
-  unsigned* qbase = tfc_queue_counters();
-  if (!qbase) return hipErrorInvalidSymbol;
-  unsigned* qctr = qbase + (size_t)(seq++ % TFC_QSETS) * TFC_QPOOLS * 16;
-  const int npool = ncu < TFC_QPOOLS ? ncu : TFC_QPOOLS;
-  const int nst = (d.Cin_pad * 2 / 64) * d.nplanes;
-  const int mfma_cycles = nst * TapPat<PAT>::ROWS * TapPat<PAT>::COLS * 2 * MT * NT * 32;   // one wave's matrix-pipe time per tile
-  static const int stagger_env = [] { const char* e = getenv("TFC_STAGGER"); return e ? atoi(e) : -1; }();
-  int stagger = (nwork >= 3 * cap) ? mfma_cycles + 5000 : 0;
-  if (stagger_env >= 0) stagger = stagger_env == 0 ? 0 : (stagger_env == 1 ? mfma_cycles + 5000 : stagger_env);
-  const int lds_q = lds;
-  TFC_LAUNCH((tfc_igemm2_kernel<MT, NT, WM, WN, PAT>), dim3(nwork < cap ? nwork : cap), dim3(256), lds_q, st, d, (const bf16_t*)in, (const uint4*)wp,
-             (bf16_t*)out, bias, stats, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork, qctr, npool, stagger);
+  TFC_LAUNCH((tfc_igemm2_kernel<MT, NT, WM, WN, PAT>), dim3(nwork < cap ? nwork : cap), dim3(256), lds, st, d, (const bf16_t*)in, (const uint4*)wp,
+             (bf16_t*)out, bias, stats, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork);
   return hipGetLastError();
 }
 template <int MT, int NT, int WM, int WN>
