@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["patch16", "glo16"], default="patch16",
+                    help="patch16 = BASELINE.json configs[1] (the metric's configuration); glo16 = configs[2] (TFCGAN_multigpu_globalFFT_16P.py: "
+                         "whole-image FFT loss instead of the 16 patch FFTs)")
     args = ap.parse_args()
 
     import torch
@@ -122,7 +125,7 @@ def main():
     D = T.Discriminator1((3, 256, 256)).to(dev)
     G.apply(T.weights_init_normal)
     D.apply(T.weights_init_normal)
-    ts = T.TrainStep(G, D, compute_dtype=torch.bfloat16)
+    ts = T.TrainStep(G, D, compute_dtype=torch.bfloat16, fft_mode="patch" if args.config == "patch16" else "global")
     A, B = T.synthetic_pairs(args.batch, seed=1234 + rank)      # the product's own recipe: oracle/ is used by the checker legs only
     A, B = A.to(dev), B.to(dev)
 
@@ -163,8 +166,10 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "PATCH-16 256x256 bf16, batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
-                                   "G step + D step, 16-patch triplet + patch-FFT loss, Adam",
+            "config": {"workload": ("PATCH-16 256x256 bf16, batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
+                                    "G step + D step, 16-patch triplet + patch-FFT loss, Adam") if args.config == "patch16" else
+                                   ("GLO-16 (TFCGAN_multigpu_globalFFT_16P.py) 256x256 bf16, batch 32 per GPU (BASELINE.json configs[2]): "
+                                    "G step + D step, 16-patch triplet + whole-image FFT loss, Adam"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_image": T.TrainStep.STEP_GFLOP},
             "roofline": {"bound": "mfma", "kernel": "tfc_igemm_kernel (halo-staged implicit-GEMM conv: fwd/dgrad/convT/upconv)",

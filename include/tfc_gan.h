@@ -138,7 +138,10 @@ int tfc_patch16_triplet(void* stream, const float* fake, const float* real, cons
  * img: fp32 [N][C][rows][rs] window grid: S in {64,256}; windows per image = wins_x*wins_y tiles of S x S starting at the
  * image origin; amp/pha: [N*wins][S][S/2+1] fp32; shift != 0 applies np.fft.fftshift to both axes. */
 int tfc_fft_spectrum(void* stream, const float* img, long long batch_stride, long long chan_stride, int row_stride, int C, int S,
-                     int wins_x, int wins_y, int N, float* amp, float* pha, int shift);
+                     int wins_x, int wins_y, int N, float* amp, float* pha, int shift, void* ws);
+/* ws: tfc_fft_spectrum_ws_bytes(S, N * wins_x * wins_y) bytes of scratch (row-transformed half spectra) -> radix-4 FFT in LDS (rows, then
+ * columns); ws == NULL -> direct DFT (S^2 work per output row: fine for one 64 x 64 window, 1 ms per call for 32 whole 256 x 256 images). */
+size_t tfc_fft_spectrum_ws_bytes(int S, int nwin);
 /* evaluation metric of TFC-GAN-FFT/Devcom_MagMSE.py:91-118 (mse_spec): per window MSE(log|fft2(a)|, log|fft2(b)|) over the FULL S x S
  * spectrum, computed from the half spectra amp_a / amp_b [nwin][S][S/2+1] of tfc_fft_spectrum; out[nwin] */
 int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out);

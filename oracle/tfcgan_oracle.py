@@ -200,6 +200,17 @@ def spectrum_components(luma):
     return np.abs(f), np.arctan2(f.imag, f.real)
 
 
+def make_spectra(luma):
+    """FFT_Components.make_spectra (P16:284-289): log|fftshift(fft2(uint8 luma))| (float64), the FULL S x S magnitude spectrum."""
+    return np.log(np.abs(np.fft.fftshift(np.fft.fft2(luma))))
+
+
+def sample_spectra(thermal_tensor):
+    """P16:378-388: per sample ToPILImage -> L -> make_spectra -> torch.Tensor (float32); [N,1,H,W]."""
+    out = [torch.tensor(make_spectra(pil_luma(to_pil_uint8(thermal_tensor[t]))), dtype=torch.float32) for t in range(thermal_tensor.shape[0])]
+    return torch.stack(out)[:, None]
+
+
 def fft_components(thermal_tensor, patch=True):
     """P16:293-319 / G16:294-313: per sample ToPILImage -> L -> components -> float32; [N,1,S,S//2+1]."""
     amps, phas = [], []

@@ -507,3 +507,26 @@ def test_adam_vs_oracle():
         ops.adam_step(pd, g.to(DEV), md, vd, 2e-4, 0.5, 0.999, 1e-8, step)
         p, m, v = O.adam_step(p, g, m, v, step)
         assert torch.allclose(pd.cpu(), p, atol=1e-7) and torch.allclose(md.cpu(), m, atol=1e-7)
+
+
+@pytest.mark.parametrize("S,wx,wy,N,shift", [(64, 4, 4, 3, False), (64, 1, 1, 2, True), (256, 1, 1, 3, False), (256, 1, 1, 2, True)])
+def test_fft_path_matches_direct_dft_and_numpy(S, wx, wy, N, shift):
+    """the LDS radix-4 FFT (rows as packed real pairs, then columns) against the direct-DFT kernel it replaces and against numpy's float64
+    rfft2 of the same uint8 luma (the reference's FFT_Components.make_components, P16:276-282 / G16)"""
+    x, _ = O.synthetic_pairs(N, seed=300 + S)
+    x = (torch.tanh(x * 1.7) * 0.999).to(DEV)
+    a1, p1 = ops.fft_spectrum(x, S, wx, wy, shift=shift)
+    a0, p0 = ops.fft_spectrum(x, S, wx, wy, shift=shift, direct=True)
+    scale = a0.max().item()
+    assert (a1 - a0).abs().max().item() <= 2e-6 * scale
+    big = a0 > 1e-3 * scale                                     # phase of a near-zero bin is noise in any arithmetic
+    dp = (p1 - p0).abs()
+    dp = torch.minimum(dp, 2 * np.pi - dp)
+    assert dp[big].max().item() <= 2e-3
+    # numpy float64 on window 0 of image 0
+    luma = O.pil_luma(O.to_pil_uint8(x[0, :, :S, :S].cpu()))
+    f = np.fft.rfft2(luma)
+    if shift:
+        f = np.fft.fftshift(f)
+    want = torch.from_numpy(np.abs(f).astype(np.float32))
+    assert (a1[0].cpu() - want).abs().max().item() <= 4e-6 * scale

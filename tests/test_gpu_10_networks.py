@@ -292,3 +292,90 @@ def test_trainstep_sees_load_state_dict():
     assert (o1["fake_B"] - o2["fake_B"]).abs().max().item() <= 1e-4      # fp32 statistics atomics: summation order differs run to run
     for k in ("loss_G", "loss_D"):
         assert abs(float(o1[k]) - float(o2[k])) <= 1e-4 * max(1.0, abs(float(o2[k]))), k
+
+
+def test_glo16_train_step_fp32_vs_reference_golden(golden):
+    """config C3 (GLO-16, TFCGAN_multigpu_globalFFT_16P.py): TrainStep(fft_mode="global") at N = 1 in exact-fp32 mode against one step of the
+    networks and whole-image fft_components lifted from the G16 script itself (G16:294-313, :524-534)"""
+    g = golden("train_step_glo16")
+    T.set_compute_dtype(torch.float32)
+    G = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=61).to(DEV).eval()
+    D = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=62).to(DEV).train()
+    w0 = G.state_dict()["final.2.weight"].clone()
+    A, B = O.synthetic_pairs(1, seed=64)
+    ts = T.TrainStep(G, D, compute_dtype=torch.float32, fft_mode="global")
+    out = ts.step(A.to(DEV), B.to(DEV), neg_idx=g["neg_idx"].tolist())
+    torch.cuda.synchronize()
+    for k in ("loss_G", "loss_GAN_g", "loss_triplet_patch", "loss_FFT", "loss_Amp", "loss_Pha", "loss_D"):
+        want = float(g[k])
+        # phase L1: the phase of a near-zero bin is round-off in ANY arithmetic (fp32 radix-4 FFT here, float64 pocketfft in the reference);
+        # on this image that moves the mean |phase difference| by 2e-4 relative -- stated tolerance 5e-4 for the phase term and what contains it
+        tol = 5e-4 if k in ("loss_Pha", "loss_FFT") else 2e-4
+        assert abs(float(out[k]) - want) <= tol * max(1.0, abs(want)), (k, float(out[k]), want)
+    assert (out["fake_B"].cpu()[:, :, ::8, ::8] - t(g["fake_sub"])).abs().mean().item() <= 1e-4
+    want = t(g["g_grad_down1"]).double()
+    rel = ((ts.gflat.grad_views["down1.model.0.weight"].cpu().double() - want).norm() / want.norm()).item()
+    assert rel <= 1e-2, rel
+    got = (G.state_dict()["final.2.weight"] - w0).cpu()
+    assert (got - t(g["g_delta_final_w"])).abs().mean().item() <= 2e-6
+
+
+def test_glo16_step_full_size_batch32_bf16():
+    """config C3 at BASELINE size (batch 32, 256x256, bf16): the global-FFT step runs on the HIP path; size-independent properties: finite
+    losses, loss_G = 0.5 GAN + triplet + 0.01 FFT (G16:534), FFT loss of identical images = 0, the whole-image spectrum of a constant image is
+    a single DC bin, and the batched loss equals the mean of per-sample losses (every term is a batch mean)"""
+    T.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    N = 32
+    A, B = O.synthetic_pairs(N, seed=98)
+    A, B = A.to(DEV), B.to(DEV)
+    G = T.GeneratorUNet((3, 256, 256)).to(DEV)
+    D = T.Discriminator1((3, 256, 256)).to(DEV)
+    G.apply(T.weights_init_normal)
+    D.apply(T.weights_init_normal)
+    ts = T.TrainStep(G, D, fft_mode="global")
+    out = ts.step(A, B)
+    torch.cuda.synchronize()
+    for k, v in out.items():
+        if k != "fake_B":
+            assert np.isfinite(float(v)), k
+    lg = 0.5 * out["loss_GAN_g"] + out["loss_triplet_patch"] + 0.01 * out["loss_FFT"]
+    assert abs(float(lg) - float(out["loss_G"])) <= 1e-4 * abs(float(lg))
+    fake = out["fake_B"]
+    z, _, _ = T.global_fft_loss(fake, fake)
+    assert z.item() == 0.0
+    full, la, lp = T.global_fft_loss(fake, B)
+    per = torch.stack([T.global_fft_loss(fake[i:i + 1], B[i:i + 1])[0] for i in range(0, N, 8)])
+    sub, _, _ = T.global_fft_loss(fake[0:N:8], B[0:N:8])
+    assert abs(per.mean().item() - sub.item()) <= 1e-4 * abs(sub.item())
+    assert abs(float(out["loss_FFT"]) - full.item()) <= 1e-5 * abs(full.item())
+    # the oracle on two of the 32 samples (CPU rfft2 of 256x256 is cheap): amplitude / phase L1 of the engine's own fake_B
+    want, wa, wp = O.global_fft_loss(fake[:2].cpu(), B[:2].cpu())
+    got, ga, gp = T.global_fft_loss(fake[:2], B[:2])
+    assert abs(ga.item() - float(wa)) <= 2e-4 * float(wa) and abs(gp.item() - float(wp)) <= 2e-3 * float(wp) + 1e-4
+    const = torch.full((1, 3, 256, 256), 0.5, device=DEV)
+    amp, pha = T.fft_components(const, patch=False)
+    assert amp.shape == (1, 1, 256, 129)
+    dc = amp[0, 0, 128, 64].item()                                 # fftshift over both axes puts DC at (128, 64)
+    assert abs(dc - 127 * 256 * 256) < 1 and (amp.sum().item() - dc) < 1e-2 * dc
+
+
+def test_sample_spectra_and_mse_spec_vs_reference_goldens(golden):
+    """FFT_Components.make_spectra / sample_spectra (P16:284-289, :378-388) and the evaluation metric mse_spec (Devcom_MagMSE.py:91-118),
+    both against outputs of the reference's own (lifted) functions"""
+    g = golden("spectra")
+    x, _ = O.synthetic_pairs(2, seed=81)
+    x = torch.tanh(x * 1.2) * 0.999 + 1e-3
+    spec = T.sample_spectra(x.to(DEV)).cpu()
+    assert spec.shape == (2, 1, 256, 256)
+    assert (spec[:, :, ::4, ::4] - t(g["spec_sub"])).abs().max().item() <= 2e-3      # log of an fp32 direct-DFT magnitude vs float64 pocketfft
+    assert (spec[1, 0, 7, :] - t(g["spec_row7"])).abs().max().item() <= 2e-3
+    assert abs(spec.mean().item() - float(g["spec_mean"])) <= 1e-4
+    one = T.FFT_Components(x[0].to(DEV)).make_spectra().cpu()
+    assert torch.equal(one, spec[0, 0])
+    gm = golden("mse_spec")
+    rng = np.random.default_rng(91)
+    base = rng.integers(1, 256, size=(3, 256, 256)).astype(np.uint8)
+    other = np.clip(base.astype(np.int32) + rng.integers(-40, 41, size=base.shape), 1, 255).astype(np.uint8)
+    got = T.mse_spec(base, other).cpu().numpy()
+    np.testing.assert_allclose(got, gm["values"], rtol=2e-3)

@@ -165,3 +165,41 @@ def test_train_step(golden):
     assert torch.allclose(G.state_dict()["down1.model.0.weight"] - gb["down1.model.0.weight"], t(g["g_delta_down1"]), atol=1e-6)
     assert torch.allclose(D.state_dict()["model.13.weight"] - db["model.13.weight"], t(g["d_delta_head"]), atol=1e-6)
     assert torch.allclose(D.state_dict()["model.3.parametrizations.weight.0._u"], t(g["d_u3"]), atol=1e-5)
+
+
+def test_glo16_train_step_matches_lifted_reference(golden):
+    """config C3: the oracle's TrainStep(fft_mode="global") against one step of the networks / fft_components lifted from
+    TFCGAN_multigpu_globalFFT_16P.py itself (G16:294-313, :524-534)"""
+    g = golden("train_step_glo16")
+    torch.set_num_threads(8)
+    G = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=61).eval()
+    D = O.init_weights_portable(O.Discriminator1((3, 256, 256)), seed=62).train()
+    A, B = O.synthetic_pairs(1, seed=64)
+    w0 = G.state_dict()["final.2.weight"].clone()
+    out = O.TrainStep(G, D, fft_mode="global").step(A, B, g["neg_idx"].tolist())
+    for k in ("loss_G", "loss_GAN_g", "loss_triplet_patch", "loss_FFT", "loss_Amp", "loss_Pha", "loss_D"):
+        assert abs(float(out[k]) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
+    assert torch.allclose(out["fake_B"][:, :, ::8, ::8], t(g["fake_sub"]), atol=1e-6)
+    assert torch.allclose(G.state_dict()["final.2.weight"] - w0, t(g["g_delta_final_w"]), atol=1e-7)
+
+
+def test_sample_spectra_matches_lifted_reference(golden):
+    """FFT_Components.make_spectra / sample_spectra (P16:284-289, :378-388)"""
+    g = golden("spectra")
+    x, _ = O.synthetic_pairs(2, seed=81)
+    x = torch.tanh(x * 1.2) * 0.999 + 1e-3
+    spec = O.sample_spectra(x)
+    assert spec.shape == (2, 1, 256, 256)
+    assert torch.allclose(spec[:, :, ::4, ::4], t(g["spec_sub"]), atol=1e-5)
+    assert torch.allclose(spec[1, 0, 7, :], t(g["spec_row7"]), atol=1e-5)
+    assert abs(float(spec.mean()) - float(g["spec_mean"])) <= 1e-5
+
+
+def test_mse_spec_matches_lifted_reference(golden):
+    """evaluation metric Devcom_MagMSE.py:91-118 (lifted with scipy.fft / sklearn as the script imports them)"""
+    g = golden("mse_spec")
+    rng = np.random.default_rng(91)
+    base = rng.integers(1, 256, size=(3, 256, 256)).astype(np.uint8)
+    other = np.clip(base.astype(np.int32) + rng.integers(-40, 41, size=base.shape), 1, 255).astype(np.uint8)
+    got = [O.mse_spec(base[i], other[i]) for i in range(3)]
+    np.testing.assert_allclose(got, g["values"], rtol=1e-5)

@@ -83,7 +83,8 @@ PROTOTYPES = {
                                             _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i), _vp, _i]),
     "tfc_spectral_norm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "tfc_patch16_triplet": (_i, [_vp, _vp, _vp, _c.POINTER(_i), _i, _i, _vp, _vp, _f]),
-    "tfc_fft_spectrum": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
+    "tfc_fft_spectrum": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "tfc_fft_spectrum_ws_bytes": (_sz, [_i, _i]),
     "tfc_logmag_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tfc_vectorize_temps": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _vp, _vp]),
     "tfc_row_triplet": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),

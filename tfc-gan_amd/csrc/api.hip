@@ -47,7 +47,8 @@ hipError_t tfc_launch_axpby(float* out, const float* x, const float* y, long lon
 hipError_t tfc_launch_dropout_mask(unsigned char* out, long long n, unsigned seed, unsigned thresh24, hipStream_t st);
 hipError_t tfc_launch_cast(int dt, int to_f32, const void* x, void* y, long long n, hipStream_t st);
 hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int* neg_idx, int N, int C, float margin, float eps, float* loss, float* dfake, float gscale, hipStream_t st);
-hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img, int nwin, float* amp, float* pha, int shift, hipStream_t st);
+hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img, int nwin, float* amp, float* pha, int shift, void* ws, hipStream_t st);
+size_t tfc_fft_ws_bytes(int S, int nwin);
 hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st);
 hipError_t tfc_launch_probe(float* out, hipStream_t st);
 hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin, float* out, hipStream_t st);
@@ -668,10 +669,12 @@ extern "C" int tfc_patch16_triplet(void* stream, const float* fake, const float*
   CHECK_HIP(tfc_launch_triplet16(fake, real, neg_idx_host, N, C, 1.0f, 1e-6f, loss, dfake, gscale, (hipStream_t)stream), "tfc_patch16_triplet");
   return 0;
 }
+extern "C" size_t tfc_fft_spectrum_ws_bytes(int S, int nwin) { return (S == 64 || S == 256) && nwin > 0 ? tfc_fft_ws_bytes(S, nwin) : 0; }
 extern "C" int tfc_fft_spectrum(void* stream, const float* img, long long batch_stride, long long chan_stride, int row_stride, int C, int S,
-                                int wins_x, int wins_y, int N, float* amp, float* pha, int shift) {
+                                int wins_x, int wins_y, int N, float* amp, float* pha, int shift, void* ws) {
   REQUIRE(img && amp && pha && (S == 64 || S == 256) && (C == 1 || C == 3) && wins_x > 0 && wins_y > 0 && N > 0, "bad args");
-  CHECK_HIP(tfc_launch_spectrum(img, batch_stride, chan_stride, row_stride, C, S, wins_x, wins_x * wins_y, N * wins_x * wins_y, amp, pha, shift, (hipStream_t)stream), "tfc_fft_spectrum");
+  if (ws) { if (int e = check_ptr16(ws, "ws")) return e; }
+  CHECK_HIP(tfc_launch_spectrum(img, batch_stride, chan_stride, row_stride, C, S, wins_x, wins_x * wins_y, N * wins_x * wins_y, amp, pha, shift, ws, (hipStream_t)stream), "tfc_fft_spectrum");
   return 0;
 }
 extern "C" int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out) {

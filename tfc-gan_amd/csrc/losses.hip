@@ -264,9 +264,167 @@ hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int*
 }
 
 // S in {64, 256}; windows = N * wins_per_img; amp/pha: [windows][S][S/2+1]
+
+// ---------------------------------------------------------------------------------------------------
+// The same spectra by FFT (S = 64 or 256 = 4^3 / 4^4): radix-4 Stockham autosort passes in LDS, no bit reversal, exact sincospi twiddle table.
+// The direct DFT above costs S^2 MACs per output row; at S = 256 (GLO-16, G16:294-313) that was 1.04 ms per call = 15 % of the GLO-16 step.
+//   pass 1 (rows)   : a workgroup owns 32 consecutive rows of one window; two REAL rows are packed into one complex transform
+//                     (z = row0 + i row1;  R0[k] = (Z[k] + conj Z[S-k]) / 2,  R1[k] = (Z[k] - conj Z[S-k]) / 2i); the half spectra go through an
+//                     LDS tile to the scratch  T[window][kx][y]  (transposed, so that pass 2 reads whole columns as contiguous runs);
+//   pass 2 (columns): complex transforms of CB columns per workgroup; amp = |F|, pha = atan2(Im, Re) (Im forced to +0 at the four self-conjugate
+//                     bins, as the direct kernel does), staged in LDS and stored with the optional fftshift of both axes.
+// One transform is carried by S/4 lanes (one radix-4 butterfly each per pass): a wave runs one 256-point or four 64-point transforms at a time.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(const float2 a, const float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// N-point forward transform of b0 (natural order in, natural order out); j = this lane's butterfly index 0 .. N/4-1; tw[k] = exp(-2 pi i k / N).
+// The N/4 lanes of a transform belong to ONE wave: LDS accesses of a wave execute in program order, a compiler-level fence is all that is needed.
+template <int N>
+__device__ __forceinline__ float2* tfc_fft_r4(float2* b0, float2* b1, const float2* __restrict__ tw, int j) {
+#pragma unroll
+  for (int Ns = 1; Ns < N; Ns *= 4) {
+    const int k = j & (Ns - 1);
+    const int ts = k * (N / (4 * Ns));
+    float2 v0 = b0[j], v1 = b0[j + N / 4], v2 = b0[j + N / 2], v3 = b0[j + 3 * N / 4];
+    if (Ns > 1) { v1 = cmul(v1, tw[ts]); v2 = cmul(v2, tw[2 * ts]); v3 = cmul(v3, tw[3 * ts]); }
+    const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y), a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+    const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y), a3 = make_float2(v1.y - v3.y, v3.x - v1.x);   // -i (v1 - v3)
+    const int j0 = ((j - k) << 2) + k;
+    b1[j0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+    b1[j0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+    b1[j0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+    b1[j0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float2* t = b0; b0 = b1; b1 = t;
+  }
+  return b0;
+}
+
+template <int S>
+__global__ void __launch_bounds__(256)
+tfc_fft_rows_kernel(const float* __restrict__ img, long long bs, long long cs, int rs, int C, int wins_x, int wins_per_img, float2* __restrict__ T) {
+  constexpr int NB = S / 2 + 1, G = S / 4, FPW = 64 / G, RPB = 32;          // lanes per transform, transforms per wave at a time, rows per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw = reinterpret_cast<float2*>(smem);                   // [S]
+  float2* wbuf = tw + S;                                          // [4 waves][2][FPW][S]
+  float2* tile = wbuf + 4 * 2 * FPW * S;                          // [NB][RPB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = lane / G, j = lane % G;
+  const int w = blockIdx.x / (S / RPB), y0 = (blockIdx.x % (S / RPB)) * RPB;
+  const int n = w / wins_per_img, kw = w % wins_per_img;
+  const float* base = img + (size_t)n * bs + (size_t)((kw / wins_x) * S) * rs + (kw % wins_x) * S;
+  for (int i = tid; i < S; i += 256) {
+    float sn, cn;
+    sincospif(2.f * (float)i / (float)S, &sn, &cn);
+    tw[i] = make_float2(cn, -sn);
+  }
+  __syncthreads();
+  float2* b0 = wbuf + ((wave * 2 + 0) * FPW + f) * S;
+  float2* b1 = wbuf + ((wave * 2 + 1) * FPW + f) * S;
+  auto luma = [&](int y, int x) -> float {
+    int q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = base[(size_t)(C == 1 ? 0 : c) * cs + (size_t)y * rs + x] * 255.f;
+      q[c] = ((int)v) & 255;
+    }
+    return (float)((19595 * q[0] + 38470 * q[1] + 7471 * q[2] + 32768) >> 16);
+  };
+  for (int it = 0; it < RPB / 2 / (4 * FPW); ++it) {
+    const int pr = (it * 4 + wave) * FPW + f;                     // row pair of this workgroup (0 .. 15)
+    const int ya = y0 + 2 * pr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b0[j + r * G] = make_float2(luma(ya, j + r * G), luma(ya + 1, j + r * G));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float2* Z = tfc_fft_r4<S>(b0, b1, tw, j);
+    for (int k = j; k < NB; k += G) {
+      const float2 a = Z[k], b = Z[(S - k) & (S - 1)];
+      tile[k * RPB + 2 * pr] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+      tile[k * RPB + 2 * pr + 1] = make_float2(0.5f * (a.y + b.y), 0.5f * (b.x - a.x));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  float2* Tw = T + (size_t)w * NB * S;
+  for (int i = tid; i < NB * RPB; i += 256) {
+    const int kx = i / RPB, yy = i % RPB;
+    Tw[(size_t)kx * S + y0 + yy] = tile[i];
+  }
+}
+
+template <int S, int CB>
+__global__ void __launch_bounds__(256)
+tfc_fft_cols_kernel(const float2* __restrict__ T, float* __restrict__ amp, float* __restrict__ pha, int shift) {
+  constexpr int NB = S / 2 + 1, G = S / 4, FPW = 64 / G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw = reinterpret_cast<float2*>(smem);                   // [S]
+  float2* wbuf = tw + S;                                          // [4 waves][2][FPW][S]
+  float* ta = reinterpret_cast<float*>(wbuf + 4 * 2 * FPW * S);   // [S][CB] amplitude
+  float* tp = ta + S * CB;                                        // [S][CB] phase
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = lane / G, j = lane % G;
+  constexpr int NCB = (NB + CB - 1) / CB;
+  const int w = blockIdx.x / NCB, c0 = (blockIdx.x % NCB) * CB;
+  for (int i = tid; i < S; i += 256) {
+    float sn, cn;
+    sincospif(2.f * (float)i / (float)S, &sn, &cn);
+    tw[i] = make_float2(cn, -sn);
+  }
+  __syncthreads();
+  float2* b0 = wbuf + ((wave * 2 + 0) * FPW + f) * S;
+  float2* b1 = wbuf + ((wave * 2 + 1) * FPW + f) * S;
+  for (int it = 0; it < CB / (4 * FPW); ++it) {
+    const int ci = (it * 4 + wave) * FPW + f;
+    const int c = c0 + ci;
+    if (c < NB) {                                                 // uniform per group of G lanes (a whole wave when FPW == 1)
+      const float2* src = T + ((size_t)w * NB + c) * S;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b0[j + r * G] = src[j + r * G];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float2* F = tfc_fft_r4<S>(b0, b1, tw, j);               // columns past the half spectrum transform stale LDS: results unused
+    if (c < NB)
+      for (int ky = j; ky < S; ky += G) {
+        float re = F[ky].x, im = F[ky].y;
+        if ((c == 0 || c == S / 2) && (ky == 0 || ky == S / 2)) im = 0.f;
+        ta[ky * CB + ci] = sqrtf(re * re + im * im);
+        tp[ky * CB + ci] = atan2f(im, re);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  for (int i = tid; i < S * CB; i += 256) {
+    const int ky = i / CB, ci = i % CB, c = c0 + ci;
+    if (c >= NB) continue;
+    int oy = ky, ox = c;
+    if (shift) { oy = (ky + S / 2) % S; ox = (c + NB / 2) % NB; }
+    const size_t oi = ((size_t)w * S + oy) * NB + ox;
+    amp[oi] = ta[i];
+    pha[oi] = tp[i];
+  }
+}
+
+size_t tfc_fft_ws_bytes(int S, int nwin) { return (size_t)nwin * (S / 2 + 1) * S * sizeof(float2); }
+template <int S, int CB>
+static hipError_t launch_fft_t(const float* img, long long bs, long long cs, int rs, int C, int wins_x, int wins_per_img, int nwin, float* amp,
+                               float* pha, int shift, void* ws, hipStream_t st) {
+  constexpr int NB = S / 2 + 1, FPW = 64 / (S / 4);
+  const size_t lds_r = (size_t)(S + 4 * 2 * FPW * S + NB * 32) * sizeof(float2);
+  const size_t lds_c = (size_t)(S + 4 * 2 * FPW * S) * sizeof(float2) + (size_t)2 * S * CB * sizeof(float);
+  hipLaunchKernelGGL((tfc_fft_rows_kernel<S>), dim3(nwin * (S / 32)), dim3(256), lds_r, st, img, bs, cs, rs, C, wins_x, wins_per_img, (float2*)ws);
+  hipLaunchKernelGGL((tfc_fft_cols_kernel<S, CB>), dim3(nwin * ((NB + CB - 1) / CB)), dim3(256), lds_c, st, (const float2*)ws, amp, pha, shift);
+  return hipGetLastError();
+}
 hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int rs, int C, int S, int wins_x, int wins_per_img,
-                               int nwin, float* amp, float* pha, int shift, hipStream_t st) {
-  if (S == 64) {
+                               int nwin, float* amp, float* pha, int shift, void* ws, hipStream_t st) {
+  if (ws && S == 64) return launch_fft_t<64, 16>(img, bs, cs, rs, C, wins_x, wins_per_img, nwin, amp, pha, shift, ws, st);
+  if (ws && S == 256) return launch_fft_t<256, 8>(img, bs, cs, rs, C, wins_x, wins_per_img, nwin, amp, pha, shift, ws, st);
+  if (S == 64) {                                                  // no scratch given: direct DFT (also the independent cross-check of the FFT path)
     constexpr int KG = 33;
     const size_t lds = 64 * 64 + 2 * 64 * 4 + 64 * KG * 2 * 4;
     hipLaunchKernelGGL((tfc_spectrum_kernel<64, KG>), dim3(nwin, 1), dim3(256), lds, st, img, bs, cs, rs, C, wins_x, wins_per_img, amp, pha, shift);

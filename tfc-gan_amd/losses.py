@@ -106,6 +106,31 @@ class FFT_Components(object):
         amp, pha = ops.fft_spectrum(t[None].expand(1, 3 if t.shape[0] == 3 else 1, S, S).contiguous(), S, 1, 1, shift=True)
         return amp[0], pha[0]
 
+    def make_spectra(self):
+        """reference :284-289: log|fftshift(fft2(image))|, the full S x S magnitude spectrum (S = 64 or 256), fp32 on the GPU."""
+        t = self._as_tensor().cuda()
+        S = t.shape[-1]
+        return _full_log_spectrum(t[None].expand(1, 3 if t.shape[0] == 3 else 1, S, S).contiguous(), S)[0]
+
+
+def _full_log_spectrum(img, S):
+    """log-magnitude of the fftshifted FULL spectrum from the half spectrum of tfc_fft_spectrum: for real input |F[ky][kx]| = |F[-ky][-kx]|, so
+    columns S/2+1 .. S-1 are the point reflection of columns S/2-1 .. 1 (pure indexing, no arithmetic beyond the kernel's)."""
+    amp, _ = ops.fft_spectrum(img, S, 1, 1, shift=False)          # [N][S][S/2+1], unshifted
+    nb = S // 2 + 1
+    ky = torch.arange(S, device=amp.device)
+    neg_ky = (-ky) % S
+    right = amp[:, neg_ky][:, :, 1:nb - 1].flip(-1)               # kx = S/2+1 .. S-1  <-  conj partner (S-ky, S-kx)
+    full = torch.cat((amp, right), dim=-1)                        # [N][S][S], kx = 0 .. S-1
+    return torch.log(torch.fft.fftshift(full, dim=(-2, -1)))
+
+
+def sample_spectra(thermal_tensor):
+    """reference :378-388: thermal_tensor [N,3,S,S] in [-1,1] -> log-magnitude spectra [N,1,S,S] fp32 (S = 64 or 256) for the sample grids."""
+    S = thermal_tensor.shape[-1]
+    assert thermal_tensor.shape[-2] == S and S in (64, 256)
+    return _full_log_spectrum(thermal_tensor.detach(), S)[:, None]
+
 
 def fft_components(thermal_tensor, patch=True):
     """reference :293-319. thermal_tensor [N,3,S,S] in [-1,1] -> (AMP, PHA) each [N,1,S,S//2+1] fp32, fftshifted.

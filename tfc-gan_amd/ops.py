@@ -348,8 +348,12 @@ def patch16_triplet(fake, real, neg_idx, want_grad=True, gscale=1.0):
     return loss, dfake
 
 
-def fft_spectrum(img, S, wins_x, wins_y, shift=True):
-    """img: fp32 [N,C,H,W] (any strides on N/C/H, unit stride on W). Returns amp, pha [N*wins_x*wins_y, S, S//2+1]."""
+_FFT_WS = {}
+
+
+def fft_spectrum(img, S, wins_x, wins_y, shift=True, direct=False):
+    """img: fp32 [N,C,H,W] (any strides on N/C/H, unit stride on W). Returns amp, pha [N*wins_x*wins_y, S, S//2+1].
+    direct=True: the direct-DFT kernel (no scratch) instead of the LDS radix-4 FFT -- the tests cross-check the two."""
     require_gpu(img)
     if img.dtype != torch.float32:
         img = img.float()
@@ -360,8 +364,15 @@ def fft_spectrum(img, S, wins_x, wins_y, shift=True):
     nwin = N * wins_x * wins_y
     amp = torch.empty((nwin, S, S // 2 + 1), dtype=torch.float32, device=img.device)
     pha = torch.empty_like(amp)
+    ws = None
+    if not direct:
+        need = lib().tfc_fft_spectrum_ws_bytes(S, nwin)
+        key = (img.device, torch.cuda.current_stream().cuda_stream)   # one scratch per (device, stream): calls on a stream are ordered
+        ws = _FFT_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _FFT_WS[key] = torch.empty(need, dtype=torch.uint8, device=img.device)
     check(lib().tfc_fft_spectrum(stream_ptr(), _p(img), img.stride(0), img.stride(1), img.stride(2), C, S, wins_x, wins_y, N,
-                                 _p(amp), _p(pha), 1 if shift else 0), "tfc_fft_spectrum")
+                                 _p(amp), _p(pha), 1 if shift else 0, _p(ws)), "tfc_fft_spectrum")
     return amp, pha
 
 
