@@ -355,6 +355,129 @@ class TrainStep:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# bf16-STORAGE mode of the step: the same algorithm with a round-to-bf16 at exactly the points where the HIP engine stores a bf16
+# tensor (tfc-gan_amd/nets.py), fp32 arithmetic in between -- what "bf16 storage, fp32 accumulate" means.  Against the plain fp32
+# oracle a bf16 run differs by ~20 % in generator gradients (activation masks flip on bf16-rounded pre-activations); against THIS
+# mode only accumulation order and rare 1-ulp rounding ties are left, so the bf16 parity test can be tight.
+#   forward rounding points : inputs (cat(A,B) / A as bf16 NHWC), packed weights, every conv / convT output, every pooled / blurred /
+#                             normalised tensor, the PatchGAN logits; NOT the generator output (fp32 NCHW from the head kernel)
+#   backward rounding points: every gradient tensor the engine stores in bf16 = the gradient AT each forward rounding point of an
+#                             activation (weight gradients and the gradient w.r.t. fake_B are fp32)
+# ---------------------------------------------------------------------------------------------------------------
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundBoth(torch.autograd.Function):                       # stored activation: value and its gradient are bf16 tensors
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+class _RoundFwd(torch.autograd.Function):                        # bf16 operand whose gradient stays fp32 (weights, fake_B into D)
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):                        # fp32 value whose gradient is stored in bf16
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+def _blur(x, stride):
+    c = x.shape[1]
+    k = torch.tensor(BLUR_TAPS)
+    filt = (torch.outer(k, k) / 64.0)[None, None].repeat(c, 1, 1, 1)
+    return F.conv2d(F.pad(x, (1, 2, 1, 2), mode="reflect"), filt, stride=stride, groups=c)
+
+
+def generator_forward_bf16(G, x):
+    """GeneratorUNet.forward (P16:160-174) with the engine's bf16 storage points (nets.GeneratorCore.forward); eval-mode dropout"""
+    rb, rw = _RoundBoth.apply, _RoundFwd.apply
+    h = _bf(x)
+    skips = []
+    for name, _, _, norm, _ in _DOWNS:
+        w = getattr(G, name).model[0].weight
+        z = rb(F.conv2d(h, rw(w), padding=1))                       # raw conv output (bf16), statistics of the stored values
+        if norm:
+            z = F.instance_norm(z, eps=1e-5)
+        h = rb(_blur(F.leaky_relu(z, 0.2), 2))                      # pooled output (bf16): next input and skip window
+        skips.append(h)
+    h = skips.pop()
+    for name, *_ in _UPS:
+        w = getattr(G, name).model[0].weight
+        z = rb(F.conv_transpose2d(h, rw(w), stride=2, padding=1))   # rawT
+        z = rb(_blur(z, 1))                                         # blur
+        z = rb(F.relu(F.instance_norm(z, eps=1e-5)))                # up-path window of the concat buffer
+        # the skip window's gradient is the convT dgrad (stored bf16) PLUS the down-path conv dgrad accumulated on top of it
+        h = torch.cat((z, _RoundBwd.apply(skips.pop())), dim=1)
+    conv = G.final[2]
+    u = F.pad(F.interpolate(h, scale_factor=2), (1, 0, 1, 0))
+    pre = _RoundBwd.apply(F.conv2d(u, rw(conv.weight), conv.bias, padding=1))   # d(pre-tanh) is stored bf16 (tfc_tanh_bwd_pack)
+    return torch.tanh(pre)
+
+
+def discriminator_forward_bf16(D, img_a, img_b, state, power_iter=True):
+    """Discriminator1.forward (P16:205-211) with the engine's storage points; `state`: list of [u, v] per SN block, advanced in place
+    (one power iteration per forward in training mode, as torch.nn.utils.parametrizations.spectral_norm does)"""
+    rb, rw = _RoundBoth.apply, _RoundFwd.apply
+    h = torch.cat((rw(img_a), _bf(img_b)), dim=1)
+    bi = 0
+    for m in D.model:
+        if isinstance(m, nn.Conv2d) and hasattr(m, "parametrizations"):
+            W = m.parametrizations.weight.original
+            u, v = state[bi]
+            with torch.no_grad():
+                u, v, _ = spectral_norm_step(W.detach(), u, v, power_iter=power_iter)
+            state[bi] = [u, v]
+            sigma = torch.dot(u, W.flatten(1) @ v)
+            z = _RoundBwd.apply(F.conv2d(h, rw(W), padding=1) / sigma + m.bias.view(1, -1, 1, 1))   # d z is stored bf16; z itself never is
+            h = _RoundFwd.apply(F.leaky_relu(z, 0.2))               # the conv epilogue stores the ACTIVATED tensor
+            h = rb(_blur(h, 2))
+            bi += 1
+    head = D.model[-1]
+    return rb(F.conv2d(F.pad(h, (1, 0, 1, 0)), head.weight, padding=1))   # the head kernel reads fp32 weights; logits stored bf16
+
+
+def bf16_storage_step(G, D, real_A, real_B, neg_idx, fft_mode="patch"):
+    """one step (P16:545-638 minus LPIPS / temperature) in bf16-storage arithmetic WITHOUT the optimiser update: returns the losses, fake_B and
+    the parameter gradients of both networks (dicts by state_dict key)"""
+    state = [[m.parametrizations.weight[0]._u.clone(), m.parametrizations.weight[0]._v.clone()] for m in D.model
+             if isinstance(m, nn.Conv2d) and hasattr(m, "parametrizations")]
+    gp = dict(G.named_parameters())
+    dp = dict(D.named_parameters())
+    fake = generator_forward_bf16(G, real_A)
+    pf = discriminator_forward_bf16(D, fake, real_A, state)
+    pr = discriminator_forward_bf16(D, real_B, real_A, state)
+    l_gan = loss_gan_generator(pf, pr)
+    l_trip = patch_triplet_loss(fake, real_B, neg_idx)
+    with torch.no_grad():
+        l_fft, la, lp = (patch_fft_loss if fft_mode == "patch" else global_fft_loss)(fake, real_B)
+    l_G = 0.5 * l_gan + l_trip + 0.01 * l_fft
+    gg = torch.autograd.grad(l_G, list(gp.values()), allow_unused=True)
+    pr2 = discriminator_forward_bf16(D, real_B, real_A, state)
+    pf2 = discriminator_forward_bf16(D, fake.detach(), real_A, state)
+    l_D = loss_discriminator(pr2, pf2)
+    dg = torch.autograd.grad(l_D, list(dp.values()), allow_unused=True)
+    return {"loss_G": l_G.detach(), "loss_GAN_g": l_gan.detach(), "loss_triplet_patch": l_trip.detach(), "loss_FFT": l_fft, "loss_D": l_D.detach(),
+            "fake_B": fake.detach(), "g_grads": {k: g for k, g in zip(gp, gg)}, "d_grads": {k: g for k, g in zip(dp, dg)}}
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # portable synthetic inputs / weights (SURVEY.md section 8d) -- regenerated identically on both sides of a parity test
 # ---------------------------------------------------------------------------------------------------------------
 def synthetic_pairs(n, seed=1234, size=256):

@@ -6,6 +6,7 @@ bf16 mode       : stated per test (bf16 keeps 8 significant bits; 12 layers of I
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import tfc_gan_amd as T
 from oracle import tfcgan_oracle as O
@@ -379,3 +380,143 @@ def test_sample_spectra_and_mse_spec_vs_reference_goldens(golden):
     other = np.clip(base.astype(np.int32) + rng.integers(-40, 41, size=base.shape), 1, 255).astype(np.uint8)
     got = T.mse_spec(base, other).cpu().numpy()
     np.testing.assert_allclose(got, gm["values"], rtol=2e-3)
+
+
+def _nchw(v):
+    return v.t[..., v.coff:v.coff + v.C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _rel(got, want):
+    return ((got.double() - want.double()).norm() / want.double().norm().clamp_min(1e-30)).item()
+
+
+def test_bf16_layers_teacher_forced_vs_storage_oracle():
+    """bf16 is the benchmarked dtype, and end to end a bf16 network is chaotic: a 1-ulp tie broken differently (different fp32 summation order)
+    changes 1 % of the next layer's roundings, 18 % after two more layers, everything after six -- so NO independent implementation, however
+    faithful, agrees end to end to better than ~1e-2 (scripts/debug_bf16_layers.py prints the growth). What CAN be tight is every layer on its
+    own: each layer of the bf16 engine is fed to the oracle's bf16-STORAGE model of that layer (round to bf16 where the engine stores bf16, fp32 in
+    between: oracle._RoundBoth / _RoundFwd / _RoundBwd) with the ENGINE's stored input, forward and backward: outputs, input gradients and weight
+    gradients of all 12 generator layers must agree to 1-ulp ties (rel-L2 <= 3e-3 forward, <= 1e-2 backward). A 10 % error in any bf16-only
+    kernel (first-layer conv, pooled activation, up-conv head, transposed-conv phases, fused wgrads) fails here by an order of magnitude."""
+    T.set_compute_dtype(torch.bfloat16)
+    torch.set_num_threads(16)
+    Gc = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=61).eval()
+    A, B = O.synthetic_pairs(1, seed=63)
+    core = T.nets.GeneratorCore(T.ops.DT_BF16)
+    params = {k: v.to(DEV) for k, v in Gc.state_dict().items() if k in T.nets.g_param_names()}
+    core.set_params(params)
+    core.debug = {}
+    fake, ctx = core.forward(A.to(DEV), seed=0, train=False, save=True)
+    rng = np.random.default_rng(5)
+    g_fake = torch.from_numpy(rng.standard_normal((1, 3, 256, 256)).astype(np.float32)) * 1e-3
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    core.backward(ctx, g_fake.to(DEV), grads)
+    torch.cuda.synchronize()
+    dbg = core.debug
+    rb, rw, rg = O._RoundBoth.apply, O._RoundFwd.apply, O._RoundBwd.apply
+    FWD, BWD = 3e-3, 1e-2           # observed: forward <= 1.6e-3 (most layers 5e-5), backward <= 5.3e-3
+    worst = [0.0, 0.0]
+
+    def check(tag, got, want, tol, slot):
+        r = _rel(got, want)
+        worst[slot] = max(worst[slot], r)
+        print(f"  {tag:34s} rel-L2 {r:.3e}")
+        assert r <= tol, (tag, r)
+
+    # ---- down path: layer i maps its stored input to raw (conv) and to the pooled output; backward from the engine's own g_out ----
+    skip_of = {4: "up1", 3: "up2", 2: "up3", 1: "up4", 0: "up5"}
+    x_in = _nchw(ctx.x8)[:, :3]
+    pooled = []
+    for i, (name, _, cout, norm, _) in enumerate(O._DOWNS):
+        w = getattr(Gc, name).model[0].weight.detach().clone().requires_grad_(True)
+        x = x_in.clone().requires_grad_(i > 0)
+        z = rb(F.conv2d(x, rw(w), padding=1))
+        check(f"{name} conv fwd", _nchw(ctx.raw[i]), z.detach(), FWD, 0)
+        raw_e = _nchw(ctx.raw[i])
+        zt = z + (raw_e - z).detach()                               # teacher forcing: continue from the ENGINE's stored conv output
+        zz = F.instance_norm(zt, eps=1e-5) if norm else zt
+        y = rb(O._blur(F.leaky_relu(zz, 0.2), 2))
+        if i < 5:
+            cat = ctx.cat[skip_of[i]]
+            y_e = cat.t[..., cat.t.shape[3] - cout:].float().cpu().permute(0, 3, 1, 2).contiguous()
+        else:
+            y_e = _nchw(ctx.d6)
+        check(f"{name} norm/act/pool fwd", y_e, y.detach(), FWD, 0)
+        g_out = _nchw(dbg[f"{name}.g_out"])
+        ins = [w] + ([x] if i > 0 else [])
+        gr = torch.autograd.grad(y, ins, g_out)
+        check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gr[0], BWD, 1)
+        dz = torch.autograd.grad(zt, z, torch.ones_like(z), allow_unused=True) if False else None
+        if i > 0:
+            # the engine ACCUMULATES this input gradient onto the up path's part of the skip window: g_out(prev) = bf16(g_in(up)[skip] + dgrad)
+            up = skip_of[i - 1]
+            prev_cout = O._DOWNS[i - 1][2]
+            # gradient of the concat buffer cat[up] (= output of `up`, input of the NEXT up block): the next block's g_in; cat[up5] feeds the head
+            nxt_up = {"up1": "up2", "up2": "up3", "up3": "up4", "up4": "up5"}
+            g_up = _nchw(dbg[f"{nxt_up[up]}.g_in"]) if up != "up5" else _nchw(dbg["g_u5"])
+            skip_part = g_up[:, g_up.shape[1] - prev_cout:]
+            want_prev = O._bf(skip_part + gr[1])
+            check(f"{name} dgrad (+skip accumulate)", _nchw(dbg[f"{O._DOWNS[i - 1][0]}.g_out"]), want_prev, BWD, 1)
+        pooled.append(y_e)
+        x_in = y_e
+    # ---- up path ----
+    h_in = pooled[5]
+    for j, (name, _, cout, _) in enumerate(O._UPS):
+        w = getattr(Gc, name).model[0].weight.detach().clone().requires_grad_(True)
+        x = h_in.clone().requires_grad_(True)
+        zT = rb(F.conv_transpose2d(x, rw(w), stride=2, padding=1))
+        zb = rb(O._blur(zT, 1))
+        check(f"{name} convT+blur fwd", _nchw(ctx.blur[j]), zb.detach(), FWD, 0)
+        zt = zb + (_nchw(ctx.blur[j]) - zb).detach()
+        y = rb(F.relu(F.instance_norm(zt, eps=1e-5)))
+        cat = ctx.cat[name]
+        y_e = cat.t[..., :cout].float().cpu().permute(0, 3, 1, 2).contiguous()
+        check(f"{name} norm/relu fwd", y_e, y.detach(), FWD, 0)
+        g_cat = _nchw(dbg[f"{name}.g_out"])
+        gw, gx = torch.autograd.grad(y, [w, x], g_cat[:, :cout])
+        check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gw, BWD, 1)
+        check(f"{name} dgrad", _nchw(dbg[f"{name}.g_in"]), O._bf(gx), BWD, 1)
+        h_in = cat.t.float().cpu().permute(0, 3, 1, 2).contiguous()   # whole concat buffer = next input
+    # ---- head: upsample + pad + conv + tanh (weights of collapsed taps are summed in fp32 and rounded ONCE: compare in that arithmetic) ----
+    conv = Gc.final[2]
+    w = conv.weight.detach().clone().requires_grad_(True)
+    b = conv.bias.detach().clone().requires_grad_(True)
+    x = h_in.clone().requires_grad_(True)
+    pre = rg(F.conv2d(F.pad(F.interpolate(x, scale_factor=2), (1, 0, 1, 0)), w, b, padding=1))
+    out = torch.tanh(pre)
+    l1 = (fake.cpu() - out.detach()).abs().mean().item()
+    print(f"  final (fp32 weights, taps rounded after collapsing in the engine): L1 {l1:.3e}")
+    assert l1 <= 1.5e-3
+    gw, gb, gx = torch.autograd.grad(out, [w, b, x], g_fake)
+    check("final wgrad", grads["final.2.weight"].cpu(), gw, BWD, 1)
+    check("final bias grad", grads["final.2.bias"].cpu(), gb, BWD, 1)
+    check("final dgrad", _nchw(dbg["g_u5"]), O._bf(gx), 2.5e-2, 1)
+    print("worst forward", worst[0], "worst backward", worst[1])
+
+
+def test_train_step_bf16_vs_bf16_storage_oracle():
+    """whole step, bf16 engine against the oracle's bf16-storage mode: the losses (2e-3) and the end-to-end numbers, stated for what they are: the
+    generator output and the gradients carry the chaotic 1-ulp divergence of twelve bf16 layers (see the teacher-forced test above for the tight,
+    per-layer statement), the 5-layer discriminator stays within a few %"""
+    T.set_compute_dtype(torch.bfloat16)
+    Gc = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=61).eval()
+    Dc = O.init_weights_portable(O.Discriminator1((3, 256, 256)), seed=62).train()
+    A, B = O.synthetic_pairs(1, seed=63)
+    neg = [3, 3, 7, 0, 4, 9, 15, 2, 8, 8, 1, 12, 5, 13, 6, 10]
+    torch.set_num_threads(16)
+    want = O.bf16_storage_step(Gc, Dc, A, B, neg)
+    G = T.GeneratorUNet((3, 256, 256)); G.load_state_dict(Gc.state_dict()); G = G.to(DEV).eval()
+    D = T.Discriminator1((3, 256, 256)); D.load_state_dict(Dc.state_dict()); D = D.to(DEV).train()
+    ts = T.TrainStep(G, D, compute_dtype=torch.bfloat16)
+    out = ts.step(A.to(DEV), B.to(DEV), neg_idx=neg)
+    torch.cuda.synchronize()
+    for k in ("loss_G", "loss_GAN_g", "loss_triplet_patch", "loss_FFT", "loss_D"):
+        w = float(want[k])
+        assert abs(float(out[k]) - w) <= 3e-3 * max(1.0, abs(w)), (k, float(out[k]), w)
+    l1 = (out["fake_B"].cpu() - want["fake_B"]).abs().mean().item()
+    print(f"bf16 engine vs bf16-storage oracle: generator L1 {l1:.3e}")
+    assert l1 <= 8e-3
+    for k, g in want["d_grads"].items():
+        rel = _rel(ts.dflat.grad_views[k].cpu(), g)
+        print(f"  D {k:48s} rel-L2 {rel:.3e}")
+        assert rel <= 2e-2, (k, rel)                            # observed <= 5.7e-3

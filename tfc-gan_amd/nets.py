@@ -178,7 +178,7 @@ class GeneratorCore:
         ops.conv_dgrad(dt, OP_UPCONV, dyf, N, ctx.u5.H, ctx.u5.W, 128, ch, self.packed["final"]["dgrad"], g_cat)
         dbg = getattr(self, "debug", None)
         if dbg is not None:
-            dbg["dyf"], dbg["g_u5"] = dyf, g_cat
+            dbg["dyf"], dbg["g_u5"] = dyf, ops.View(g_cat.t.clone(), g_cat.C)   # clone: the skip window is accumulated into later
         g_skip = [None] * 6                                       # gradient window of d1..d5 (views), g_d6 separately
         for j in range(4, -1, -1):
             name, cin, cout, drop, skip = G_UP[j]
@@ -196,12 +196,15 @@ class GeneratorCore:
             ops.act_bwd(dt, 0, d_blur, None, N, H, H, cout, d_rawT, stats=None, slope=1.0, pool=1)
             key = f"{name}.model.0.weight"
             if dbg is not None:
+                dbg[f"{name}.g_out"] = ops.View(g_cat.t.clone(), g_cat.C)       # gradient of the whole concat buffer (up window | skip window)
                 dbg[f"{name}.d_blur"], dbg[f"{name}.d_rawT"] = d_blur, d_rawT
             self._ws = ops.conv_wgrad(dt, OP_CONVT, uin, d_rawT, cin, cout, grads[key], accumulate, self._ws)
             if hook:
                 hook(key)
             g_in = new_act(N, uin.H, uin.W, uin.pitch, dt, dev)
             ops.conv_dgrad(dt, OP_CONVT, d_rawT, N, uin.H, uin.W, cin, cout, self.packed[name]["dgrad"], g_in)
+            if dbg is not None:
+                dbg[f"{name}.g_in"] = ops.View(g_in.t.clone(), g_in.C)          # before the down path accumulates into its skip window
             g_cat = g_in                                          # gradient of the next concat buffer (or of d6 when j == 0)
         g_cur = g_cat                                             # = gradient of d6
         for i in range(5, -1, -1):
@@ -218,6 +221,9 @@ class GeneratorCore:
             else:
                 ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, drop_p=dp, seed=sd)
             key = down_weight_key(name)
+            if dbg is not None:
+                dbg[f"{name}.g_out"] = ops.View(g_cur.t[..., g_cur.coff:g_cur.coff + g_cur.C].clone(), g_cur.C)   # incl. the accumulated skip part
+                dbg[f"{name}.d_raw"] = d_raw
             self._ws = ops.conv_wgrad(dt, OP_CONV, din, d_raw, cin, cout, grads[key], accumulate, self._ws)
             if hook:
                 hook(key)
@@ -328,6 +334,9 @@ class DiscriminatorCore:
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             gb_img = ops.zeros_f32((N, cout), dev) if grads is not None else None
             ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
+            ddbg = getattr(self, "debug", None)
+            if ddbg is not None:
+                ddbg[f"b{bi}.g_out"], ddbg[f"b{bi}.d_raw"] = g_cur, d_raw
             W = self.params[f"model.{i}.parametrizations.weight.original"]
             if grads is not None:
                 gbias = grads[f"model.{i}.bias"]
