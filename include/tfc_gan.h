@@ -165,6 +165,22 @@ int tfc_bce_relativistic(void* stream, int dt, const void* a, const void* b, int
 int tfc_adam_step(void* stream, float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                   int step, float gscale);
 
+/* ---- STN21 configuration: TFC-STN/TFCGAN_STN21_Original_NewModel3_Official.py ("STN") ---------------- */
+/* Net.forward, STN:228-229: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(src, grid, mode='bicubic', padding_mode='border',
+ * align_corners=True), fused (the grid is never stored). src / out: fp32 NCHW [N][C][H][W]; theta: [N][2][3] (identity already added, STN:208-211). */
+int tfc_affine_warp_fwd(void* stream, const float* src, const float* theta, float* out, int N, int C, int H, int W);
+/* backward: dtheta[N][6] = d loss / d theta (the trainable path: theta comes from the localiser); dsrc (nullable) = d loss / d src. Both are
+ * overwritten (zeroed inside). gout: d loss / d out. */
+int tfc_affine_warp_bwd(void* stream, const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C, int H, int W);
+/* morph_triplet, STN:444-449: kornia.morphology.gradient(x, [[0,1,0],[1,1,1],[0,1,0]]) = dilation - erosion with geodesic borders (neighbours
+ * outside the image never win). x / out: fp32, `planes` images of H x W; arg (nullable): per pixel arg-max | arg-min << 4 for the backward. */
+int tfc_morph_grad_fwd(void* stream, const float* x, float* out, uint8_t* arg, long long planes, int H, int W);
+int tfc_morph_grad_bwd(void* stream, const float* gout, const uint8_t* arg, float* dx, long long planes, int H, int W);
+/* criterion_morph = nn.TripletMarginLoss(margin=1.0, p=2) (STN:99, :457) over the last dim with its gradient w.r.t. the anchor:
+ * loss[0] = mean_rows max(margin + ||a-p+eps|| - ||a-n+eps||, 0); danchor (nullable) = gscale * d loss / d anchor. */
+int tfc_row_triplet_grad(void* stream, const float* anchor, const float* positive, const float* negative, long long rows, int W, float margin,
+                         float gscale, float* loss, float* danchor);
+
 /* ---- measurement -------------------------------------------------------------------------------------------------- */
 /* When enabled every gather-GEMM / wgrad launch is bracketed by hipEvents on its own stream; tfc_prof_collect()
  * (call after synchronising) sums them per kernel class: 0 = tfc_igemm_kernel family, 1 = tfc_wgrad family (+ slab reduce). */

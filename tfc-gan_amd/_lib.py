@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libtfcgan_hip.so")
-SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "losses.hip", "probe.hip"]
+SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "losses.hip", "stn.hip", "probe.hip"]
 HEADERS = ["common.h", "tfc_desc.h", "pack_math.h"]
 PUBLIC_HEADER = os.path.join(_ROOT, "include", "tfc_gan.h")
 
@@ -89,6 +89,11 @@ PROTOTYPES = {
     "tfc_vectorize_temps": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _vp, _vp]),
     "tfc_row_triplet": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
     "tfc_l1_sum": (_i, [_vp, _vp, _vp, _ll, _f, _vp, _i]),
+    "tfc_affine_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "tfc_affine_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "tfc_morph_grad_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
+    "tfc_morph_grad_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
+    "tfc_row_triplet_grad": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _vp, _vp]),
     "tfc_bce_relativistic": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _f]),
     "tfc_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f]),
     "tfc_prof_enable": (_i, [_i]),

@@ -56,6 +56,12 @@ hipError_t tfc_launch_vectorize_temps(const float* x, long long bs, int rs, int 
 hipError_t tfc_launch_row_triplet(const float* a, const float* p, const float* ng, long long rows, int W, float margin, float eps,
                                   float* loss, hipStream_t st);
 hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st);
+hipError_t tfc_launch_affine_warp_fwd(const float* src, const float* theta, float* out, int N, int C, int H, int W, hipStream_t st);
+hipError_t tfc_launch_affine_warp_bwd(const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C, int H, int W, hipStream_t st);
+hipError_t tfc_launch_morph_grad_fwd(const float* x, float* out, unsigned char* arg, long long planes, int H, int W, hipStream_t st);
+hipError_t tfc_launch_morph_grad_bwd(const float* gout, const unsigned char* arg, float* dx, long long planes, int H, int W, hipStream_t st);
+hipError_t tfc_launch_row_triplet_grad(const float* a, const float* p, const float* ng, long long rows, int W, float margin, float eps, float gscale,
+                                       float* loss, float* da, hipStream_t st);
 struct SnBatch {
   const float* W[4];
   float* u[4]; float* v[4]; float* sigma2[4];
@@ -692,6 +698,33 @@ extern "C" int tfc_row_triplet(void* stream, const float* anchor, const float* p
                               float margin, float* loss) {
   REQUIRE(anchor && positive && negative && loss && rows > 0 && W > 0, "bad args");
   CHECK_HIP(tfc_launch_row_triplet(anchor, positive, negative, rows, W, margin, 1e-6f, loss, (hipStream_t)stream), "tfc_row_triplet");
+  return 0;
+}
+extern "C" int tfc_affine_warp_fwd(void* stream, const float* src, const float* theta, float* out, int N, int C, int H, int W) {
+  REQUIRE(src && theta && out && N > 0 && C > 0 && H > 1 && W > 1, "bad args");
+  CHECK_HIP(tfc_launch_affine_warp_fwd(src, theta, out, N, C, H, W, (hipStream_t)stream), "tfc_affine_warp_fwd");
+  return 0;
+}
+extern "C" int tfc_affine_warp_bwd(void* stream, const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C,
+                                   int H, int W) {
+  REQUIRE(src && theta && gout && dtheta && N > 0 && C > 0 && H > 1 && W > 1, "bad args");
+  CHECK_HIP(tfc_launch_affine_warp_bwd(src, theta, gout, dtheta, dsrc, N, C, H, W, (hipStream_t)stream), "tfc_affine_warp_bwd");
+  return 0;
+}
+extern "C" int tfc_morph_grad_fwd(void* stream, const float* x, float* out, uint8_t* arg, long long planes, int H, int W) {
+  REQUIRE(x && out && planes > 0 && H > 0 && W > 0, "bad args");
+  CHECK_HIP(tfc_launch_morph_grad_fwd(x, out, arg, planes, H, W, (hipStream_t)stream), "tfc_morph_grad_fwd");
+  return 0;
+}
+extern "C" int tfc_morph_grad_bwd(void* stream, const float* gout, const uint8_t* arg, float* dx, long long planes, int H, int W) {
+  REQUIRE(gout && arg && dx && planes > 0 && H > 0 && W > 0, "bad args");
+  CHECK_HIP(tfc_launch_morph_grad_bwd(gout, arg, dx, planes, H, W, (hipStream_t)stream), "tfc_morph_grad_bwd");
+  return 0;
+}
+extern "C" int tfc_row_triplet_grad(void* stream, const float* anchor, const float* positive, const float* negative, long long rows, int W,
+                                   float margin, float gscale, float* loss, float* danchor) {
+  REQUIRE(anchor && positive && negative && loss && rows > 0 && W > 0, "bad args");
+  CHECK_HIP(tfc_launch_row_triplet_grad(anchor, positive, negative, rows, W, margin, 1e-6f, gscale, loss, danchor, (hipStream_t)stream), "tfc_row_triplet_grad");
   return 0;
 }
 extern "C" int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first) {
