@@ -32,6 +32,8 @@ extern "C" {
 #define TFC_OP_PADCONV 1  /* nn.ZeroPad2d((1,0,1,0)) + nn.Conv2d(k4,p1)       P16:201-202 (PatchGAN head)                    */
 #define TFC_OP_CONVT 2    /* nn.ConvTranspose2d(k4,s2,p1)                     P16:122 (UNetUp)                               */
 #define TFC_OP_UPCONV 3   /* nn.Upsample(x2)+nn.ZeroPad2d((1,0,1,0))+nn.Conv2d(k4,p1) [+Tanh]   P16:153-158 (generator head)  */
+#define TFC_OP_CONV3 4    /* nn.Conv2d(k3,s1,p1): VGG16 features of criterion_lpips (P16:70-73, :598). Weights are passed zero-padded to
+                             [Cout][Cin][4][4] (filter in rows / columns 0..2); forward and input gradient only (frozen network)          */
 
 /* epilogue flags of tfc_conv_fwd / tfc_conv_dgrad */
 #define TFC_EP_BIAS 1       /* + bias[Cout]                                                                                   */
@@ -39,6 +41,7 @@ extern "C" {
 #define TFC_EP_ACCUM 4      /* result += existing output (skip-connection gradient accumulation, torch.cat backward P16:133)  */
 #define TFC_EP_TANH_NCHW 8  /* nn.Tanh (P16:157) and store fp32 NCHW to `out_nchw`                                            */
 #define TFC_EP_LEAKY 16     /* nn.LeakyReLU(0.2) of Discriminator1 (P16:190) applied to the result before it is stored          */
+#define TFC_EP_RELU 32      /* nn.ReLU applied to the result before it is stored (VGG16 feature stack of LPIPS)                    */
 
 const char* tfc_last_error(void);
 int tfc_abi_version(void);
@@ -180,6 +183,25 @@ int tfc_morph_grad_bwd(void* stream, const float* gout, const uint8_t* arg, floa
  * loss[0] = mean_rows max(margin + ||a-p+eps|| - ||a-n+eps||, 0); danchor (nullable) = gscale * d loss / d anchor. */
 int tfc_row_triplet_grad(void* stream, const float* anchor, const float* positive, const float* negative, long long rows, int W, float margin,
                          float gscale, float* loss, float* danchor);
+
+/* ---- LPIPS term of loss_G: criterion_lpips = lpips.LPIPS(net_type='vgg', version='0.1'), P16:70-73, used at
+ * P16:598 inside loss_G. lpips_pytorch is a pip dependency that is absent from the reference tree; its published algorithm is restated
+ * (PARITY UNPINNED): z-score the inputs, VGG16 features at relu1_2 / 2_2 / 3_3 / 4_3 / 5_3 (3x3 convolutions = TFC_OP_CONV3 with
+ * TFC_EP_RELU), channel-normalise, squared difference, 1x1 "lin" head, spatial mean, sum over layers (and over the batch: the package
+ * returns torch.sum(torch.cat(res, 0), 0, True)). Activations NHWC in dt with pitch == C. ---- */
+/* (x - shift[c]) / scale[c], fp32 NCHW [N][C][H][W] -> NHWC channels [0,8) of a `pitch`-channel image (C <= 8; the rest zero / untouched) */
+int tfc_lpips_input_fwd(void* stream, int dt, const float* x, const float* shift, const float* scale, void* out, int N, int C, int H, int W, int pitch);
+/* dx fp32 NCHW (=/+=) alpha * g[..c] / scale[c] */
+int tfc_lpips_input_bwd(void* stream, int dt, const void* g, const float* scale, float* dx, int N, int C, int H, int W, int pitch, float alpha,
+                        int accumulate);
+/* nn.MaxPool2d(2, 2) of torchvision's vgg16.features; backward routes to the first maximum of each window */
+int tfc_maxpool2_fwd(void* stream, int dt, const void* x, void* y, int N, int H, int W, int C);
+int tfc_maxpool2_bwd(void* stream, int dt, const void* x, const void* dy, void* dx, int N, int H, int W, int C);
+/* dz = (y > 0) ? dy (+ extra, nullable) : 0 over n elements (n % 8 == 0); dz may alias dy */
+int tfc_relu_bwd(void* stream, int dt, const void* dy, const void* y, const void* extra, void* dz, long long n);
+/* one LPIPS layer: out[n] += mean_pixels sum_c w[c] (fx/(|fx|+1e-10) - fy/(|fy|+1e-10))_c^2 ; dfx (nullable) = gscale * d out[n] / d fx */
+int tfc_lpips_head(void* stream, int dt, const void* fx, const void* fy, const float* w, float* out, void* dfx, int N, int H, int W, int C,
+                   float gscale);
 
 /* ---- measurement -------------------------------------------------------------------------------------------------- */
 /* When enabled every gather-GEMM / wgrad launch is bracketed by hipEvents on its own stream; tfc_prof_collect()

@@ -45,6 +45,8 @@ def _ref(op, x, w):
         return F.conv2d(F.pad(x, (1, 0, 1, 0)), w, padding=1)
     if op == _lib.OP_CONVT:
         return F.conv_transpose2d(x, w, stride=2, padding=1)
+    if op == _lib.OP_CONV3:                              # 3x3 / stride 1 / pad 1 filter in rows/cols 0..2 of the 4x4 slot; the rest is ignored
+        return F.conv2d(x, w[:, :, :3, :3], padding=1)
     return F.conv2d(F.pad(F.interpolate(x, scale_factor=2), (1, 0, 1, 0)), w, padding=1)
 
 
@@ -66,7 +68,8 @@ def _emulate(op, pas, es, a, b, out_shape, N, H, W, Cin, Cout):
 
 CASES = [(_lib.OP_CONV, 2, 9, 19, 3, 16), (_lib.OP_CONV, 1, 20, 9, 32, 5), (_lib.OP_CONV, 1, 8, 8, 16, 40),
          (_lib.OP_PADCONV, 2, 9, 17, 32, 1), (_lib.OP_CONVT, 2, 5, 9, 16, 8), (_lib.OP_CONVT, 1, 9, 17, 32, 16),
-         (_lib.OP_UPCONV, 1, 9, 10, 32, 3), (_lib.OP_UPCONV, 2, 8, 17, 16, 3)]
+         (_lib.OP_UPCONV, 1, 9, 10, 32, 3), (_lib.OP_UPCONV, 2, 8, 17, 16, 3),
+         (_lib.OP_CONV3, 2, 9, 19, 32, 64), (_lib.OP_CONV3, 1, 8, 8, 64, 32), (_lib.OP_CONV3, 1, 6, 10, 16, 32)]
 
 
 @pytest.mark.parametrize("op,N,H,W,Cin,Cout", CASES)
@@ -74,6 +77,8 @@ CASES = [(_lib.OP_CONV, 2, 9, 19, 3, 16), (_lib.OP_CONV, 1, 20, 9, 32, 5), (_lib
 def test_gather_model_matches_torch(op, N, H, W, Cin, Cout, es):
     if (((Cin + 7) // 8 * 8) * es > 64 and (((Cin + 7) // 8 * 8) * es) % 64) or (((Cout + 7) // 8 * 8) * es > 64 and (((Cout + 7) // 8 * 8) * es) % 64):
         pytest.skip("channel count not representable in this chunk geometry")
+    if op == _lib.OP_CONV3 and ((Cin * es) % 64 or (Cout * es) % 64):
+        pytest.skip("TFC_OP_CONV3 takes whole 64-byte channel chunks only")
     rng = np.random.default_rng(op * 100 + Cin)
     x = torch.from_numpy(rng.standard_normal((N, Cin, H, W)).astype(np.float32)).requires_grad_(True)
     wshape = (Cin, Cout, 4, 4) if op == _lib.OP_CONVT else (Cout, Cin, 4, 4)

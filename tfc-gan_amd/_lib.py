@@ -12,13 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libtfcgan_hip.so")
-SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "losses.hip", "stn.hip", "probe.hip"]
+SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "losses.hip", "stn.hip", "lpips.hip", "probe.hip"]
 HEADERS = ["common.h", "tfc_desc.h", "pack_math.h"]
 PUBLIC_HEADER = os.path.join(_ROOT, "include", "tfc_gan.h")
 
 DT_BF16, DT_F32 = 0, 1
-OP_CONV, OP_PADCONV, OP_CONVT, OP_UPCONV = 0, 1, 2, 3
-EP_BIAS, EP_STATS, EP_ACCUM, EP_TANH_NCHW, EP_LEAKY = 1, 2, 4, 8, 16
+OP_CONV, OP_PADCONV, OP_CONVT, OP_UPCONV, OP_CONV3 = 0, 1, 2, 3, 4
+EP_BIAS, EP_STATS, EP_ACCUM, EP_TANH_NCHW, EP_LEAKY, EP_RELU = 1, 2, 4, 8, 16, 32
 
 _lock = threading.Lock()
 _lib = None
@@ -94,6 +94,12 @@ PROTOTYPES = {
     "tfc_morph_grad_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
     "tfc_morph_grad_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
     "tfc_row_triplet_grad": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _vp, _vp]),
+    "tfc_lpips_input_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "tfc_lpips_input_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i]),
+    "tfc_maxpool2_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i]),
+    "tfc_maxpool2_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "tfc_relu_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _ll]),
+    "tfc_lpips_head": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f]),
     "tfc_bce_relativistic": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, _vp, _vp, _f]),
     "tfc_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f]),
     "tfc_prof_enable": (_i, [_i]),

@@ -16,8 +16,20 @@
 #undef TFC_EP_STATS
 #undef TFC_EP_ACCUM
 #undef TFC_EP_TANH_NCHW
+#undef TFC_EP_LEAKY
+#undef TFC_EP_RELU
+#undef TFC_OP_CONV
+#undef TFC_OP_PADCONV
+#undef TFC_OP_CONVT
+#undef TFC_OP_UPCONV
+#undef TFC_OP_CONV3
 #include "tfc_desc.h"
 #include "pack_math.h"
+#define TFC_OP_CONV 0
+#define TFC_OP_PADCONV 1
+#define TFC_OP_CONVT 2
+#define TFC_OP_UPCONV 3
+#define TFC_OP_CONV3 4
 
 // ---- internal launchers (igemm.hip / elementwise.hip / losses.hip) ------------------------------------------
 int tfc_total_substeps(const TfcGather& d, int es);
@@ -182,7 +194,7 @@ extern "C" int tfc_prof_records(int max_records, int* kclass, double* ms, double
 // ---------------------------------------------------------------------------------------------------------------
 struct WeightMap { int Nreal, Creal; long long sn, sc; };
 
-static int out_hw(int op, int h) { return op == TFC_OP_CONV ? h - 1 : (op == TFC_OP_PADCONV ? h : 2 * h); }
+static int out_hw(int op, int h) { return op == TFC_OP_CONV ? h - 1 : ((op == TFC_OP_PADCONV || op == TFC_OP_CONV3) ? h : 2 * h); }
 static int num_phases(int op, int pass) { return ((op == TFC_OP_CONVT || op == TFC_OP_UPCONV) && pass != 1) ? 4 : 1; }
 
 static void set_tiles(TfcGather& d) {
@@ -253,6 +265,16 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
         if (wm) *wm = {Cout, Cin, (long long)Cin * 16, 16};
         break;
       }
+      case TFC_OP_CONV3: {
+        // nn.Conv2d(k3, s1, p1) (VGG16 feature stack of LPIPS): the 3 x 3 filter is handed over zero-padded to the 4 x 4 torch layout of the other
+        // ops ([Cout][Cin][4][4], taps (ky, kx) with ky, kx <= 2 used), so packing shares every code path; 3 x 3 raster = tap pattern 6
+        d.GH = OH; d.GW = OW;
+        p.dy0 = -1; p.dx0 = -1; p.hh = 10; p.hw = 18; p.ntaps = 9;
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) { const int t = ky * 3 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_mask[t] = 1 << (ky * 4 + kx); }
+        if (wm) *wm = {Cout, Cin, (long long)Cin * 16, 16};
+        break;
+      }
       default: return fail(-1, "unknown op %d", op);
     }
   } else {
@@ -269,6 +291,14 @@ static int build_desc(int op, int pass, int phase, int N, int H, int W, int Cin,
         for (int ky = 0; ky < 4; ++ky)
           for (int kx = 0; kx < 4; ++kx) { const int t = ky * 4 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_mask[t] = 1 << ((3 - ky) * 4 + (3 - kx)); }
         if (wm) *wm = {Cin, Cout, 16, (long long)Cin * 16};    // Conv2d weight [Cout][Cin][4][4], n = ci, c = co
+        break;
+      }
+      case TFC_OP_CONV3: {
+        TfcPlane& p = d.plane[0];                                 // dx[i] = sum_k dy[i + 1 - k] W[k], k = 0..2: plane offsets 0..2 from i - 1, flipped taps
+        p.dy0 = -1; p.dx0 = -1; p.hh = 10; p.hw = 18; p.ntaps = 9;
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) { const int t = ky * 3 + kx; p.tap_dy[t] = ky; p.tap_dx[t] = kx; p.tap_mask[t] = 1 << ((2 - ky) * 4 + (2 - kx)); }
+        if (wm) *wm = {Cin, Cout, 16, (long long)Cin * 16};
         break;
       }
       case TFC_OP_CONVT: {
@@ -329,18 +359,24 @@ static int check_desc(const TfcGather& d, int dt) {
 
 static int check_common(int dt, int op, int N, int H, int W, int Cin, int Cout) {
   REQUIRE(dt == TFC_DT_BF16 || dt == TFC_DT_F32, "bad dtype %d", dt);
-  REQUIRE(op >= 0 && op <= 3, "bad op %d", op);
+  REQUIRE(op >= 0 && op <= 4, "bad op %d", op);
   REQUIRE(N > 0 && H > 1 && W > 1 && Cin > 0 && Cout > 0, "bad dims N=%d H=%d W=%d Cin=%d Cout=%d", N, H, W, Cin, Cout);
   REQUIRE((long long)N * (2 * H) * (2 * W) * (long long)(pad8(Cin) > pad8(Cout) ? pad8(Cin) : pad8(Cout)) < 2147483647LL,
           "tensor exceeds 2^31 elements");
   const int es = es_of(dt);
   REQUIRE(pad8(Cin) * es <= 64 || (pad8(Cin) * es) % 64 == 0, "Cin=%d: padded channel bytes must be <= 64 or a multiple of 64", Cin);
   REQUIRE(pad8(Cout) * es <= 64 || (pad8(Cout) * es) % 64 == 0, "Cout=%d: padded channel bytes must be <= 64 or a multiple of 64", Cout);
+  // 9 taps do not fill whole 64-byte K chunks with narrow channels: the caller pads the image to 64 bytes of channels (lpips.py does)
+  REQUIRE(op != TFC_OP_CONV3 || ((pad8(Cin) * es) % 64 == 0 && (pad8(Cout) * es) % 64 == 0), "TFC_OP_CONV3 needs channel bytes in multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
   return 0;
 }
 static int check_pitch(int dt, int pitch, int cpad, const char* what) {
   const int ue = 16 / es_of(dt);
   REQUIRE(pitch >= cpad && pitch % ue == 0, "%s pitch %d must be >= %d and a multiple of %d", what, pitch, cpad, ue);
+  return 0;
+}
+static int check_dt(int dt) {
+  REQUIRE(dt == TFC_DT_BF16 || dt == TFC_DT_F32, "bad dtype %d", dt);
   return 0;
 }
 static int check_ptr16(const void* p, const char* what) {
@@ -360,7 +396,7 @@ static size_t phase_packed_offset(int dt, int op, int pass, int Cin, int Cout, i
 }
 
 extern "C" size_t tfc_conv_packed_bytes(int dt, int op, int pass, int Cin, int Cout) {
-  if (pass < 0 || pass > 1 || op < 0 || op > 3) return 0;
+  if (pass < 0 || pass > 1 || op < 0 || op > 4) return 0;
   return phase_packed_offset(dt, op, pass, Cin, Cout, num_phases(op, pass));
 }
 
@@ -380,7 +416,7 @@ extern "C" int tfc_conv_pack(void* stream, int dt, int op, int pass, const float
 
 static double conv_flop(int op, int N, int H, int W, int Cin, int Cout) {
   const double oh = out_hw(op, H), ow = out_hw(op, W);
-  const double taps = (op == TFC_OP_CONVT) ? 4.0 : 16.0;
+  const double taps = (op == TFC_OP_CONVT) ? 4.0 : (op == TFC_OP_CONV3 ? 9.0 : 16.0);
   return 2.0 * N * oh * ow * (double)Cin * Cout * taps;
 }
 
@@ -518,6 +554,7 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
   if (int e = check_pitch(dt, x_pitch, pad8(Cin), "x")) return e;
   if (int e = check_pitch(dt, dy_pitch, pad8(Cout), "dy")) return e;
   REQUIRE(ws != nullptr && dw != nullptr, "ws / dw null");
+  REQUIRE(op != TFC_OP_CONV3, "TFC_OP_CONV3 (frozen VGG features of the LPIPS term) has no weight-gradient pass");
   hipStream_t st = (hipStream_t)stream;
   WeightMap wm{};                                                // the accumulator part of ws is all-zero on entry (caller zeroes it ONCE) and again on exit
   {
@@ -727,6 +764,66 @@ extern "C" int tfc_row_triplet_grad(void* stream, const float* anchor, const flo
   CHECK_HIP(tfc_launch_row_triplet_grad(anchor, positive, negative, rows, W, margin, 1e-6f, gscale, loss, danchor, (hipStream_t)stream), "tfc_row_triplet_grad");
   return 0;
 }
+// ---- LPIPS term (lpips.hip) ------------------------------------------------------------------------------------------------------
+hipError_t tfc_launch_lpips_input(int dt, const float* x, const float* shift, const float* scale, void* out, int N, int C, long long HW, int pitch, hipStream_t st);
+hipError_t tfc_launch_lpips_input_bwd(int dt, const void* g, const float* scale, float* dx, int N, int C, long long HW, int pitch, float alpha, int accumulate, hipStream_t st);
+hipError_t tfc_launch_maxpool2(int dt, int bwd, const void* x, const void* dy, void* out, int N, int H, int W, int C, hipStream_t st);
+hipError_t tfc_launch_relu_bwd(int dt, const void* dy, const void* y, const void* extra, void* dz, long long n, hipStream_t st);
+hipError_t tfc_launch_lpips_head(int dt, const void* fx, const void* fy, const float* w, float* out, void* dfx, int N, long long HW, int C, float gscale, hipStream_t st);
+
+extern "C" int tfc_lpips_input_fwd(void* stream, int dt, const float* x, const float* shift, const float* scale, void* out, int N, int C, int H, int W,
+                                   int pitch) {
+  REQUIRE(x && shift && scale && out && N > 0 && C > 0 && C <= 8 && H > 0 && W > 0 && pitch >= 8 && pitch % 8 == 0, "bad args");
+  if (int e = check_dt(dt)) return e;
+  if (int e = check_ptr16(out, "out")) return e;
+  // the kernel writes channels [0, 8) of every pixel; channels [8, pitch) keep what the caller put there (zeros)
+  CHECK_HIP(tfc_launch_lpips_input(dt, x, shift, scale, out, N, C, (long long)H * W, pitch, (hipStream_t)stream), "tfc_lpips_input_fwd");
+  return 0;
+}
+extern "C" int tfc_lpips_input_bwd(void* stream, int dt, const void* g, const float* scale, float* dx, int N, int C, int H, int W, int pitch, float alpha,
+                                   int accumulate) {
+  REQUIRE(g && scale && dx && N > 0 && C > 0 && C <= 8 && H > 0 && W > 0 && pitch >= 8 && pitch % 8 == 0, "bad args");
+  if (int e = check_dt(dt)) return e;
+  CHECK_HIP(tfc_launch_lpips_input_bwd(dt, g, scale, dx, N, C, (long long)H * W, pitch, alpha, accumulate, (hipStream_t)stream), "tfc_lpips_input_bwd");
+  return 0;
+}
+extern "C" int tfc_maxpool2_fwd(void* stream, int dt, const void* x, void* y, int N, int H, int W, int C) {
+  REQUIRE(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0, "bad args");
+  if (int e = check_dt(dt)) return e;
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(y, "y")) return e;
+  CHECK_HIP(tfc_launch_maxpool2(dt, 0, x, nullptr, y, N, H, W, C, (hipStream_t)stream), "tfc_maxpool2_fwd");
+  return 0;
+}
+extern "C" int tfc_maxpool2_bwd(void* stream, int dt, const void* x, const void* dy, void* dx, int N, int H, int W, int C) {
+  REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0, "bad args");
+  if (int e = check_dt(dt)) return e;
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(dy, "dy")) return e;
+  if (int e = check_ptr16(dx, "dx")) return e;
+  CHECK_HIP(tfc_launch_maxpool2(dt, 1, x, dy, dx, N, H, W, C, (hipStream_t)stream), "tfc_maxpool2_bwd");
+  return 0;
+}
+extern "C" int tfc_relu_bwd(void* stream, int dt, const void* dy, const void* y, const void* extra, void* dz, long long n) {
+  REQUIRE(dy && y && dz && n > 0 && n % 8 == 0, "bad args");
+  if (int e = check_dt(dt)) return e;
+  if (int e = check_ptr16(dy, "dy")) return e;
+  if (int e = check_ptr16(y, "y")) return e;
+  if (int e = check_ptr16(dz, "dz")) return e;
+  if (extra) { if (int e = check_ptr16(extra, "extra")) return e; }
+  CHECK_HIP(tfc_launch_relu_bwd(dt, dy, y, extra, dz, n, (hipStream_t)stream), "tfc_relu_bwd");
+  return 0;
+}
+extern "C" int tfc_lpips_head(void* stream, int dt, const void* fx, const void* fy, const float* w, float* out, void* dfx, int N, int H, int W, int C,
+                              float gscale) {
+  REQUIRE(fx && fy && w && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bad args");
+  if (int e = check_dt(dt)) return e;
+  if (int e = check_ptr16(fx, "fx")) return e;
+  if (int e = check_ptr16(fy, "fy")) return e;
+  if (dfx) { if (int e = check_ptr16(dfx, "dfx")) return e; }
+  CHECK_HIP(tfc_launch_lpips_head(dt, fx, fy, w, out, dfx, N, (long long)H * W, C, gscale, (hipStream_t)stream), "tfc_lpips_head");
+  return 0;
+}
 extern "C" int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first) {
   REQUIRE(a && b && out && n > 0, "bad args");
   if (zero_first) CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream), "tfc_l1_sum memset");
@@ -767,7 +864,7 @@ extern "C" int tfc_probe_mfma(void* stream, float* out) {
 //   pass 2: x [N][H][W][pad8(Cin)], w_host = dy [N][OH][OW][pad8(Cout)] -> y = dw (torch layout)
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int tfc_host_emulate_conv(int op, int pass, int es, const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout) {
-  REQUIRE(pass >= 0 && pass <= 2 && op >= 0 && op <= 3 && (es == 2 || es == 4), "bad op/pass/es");
+  REQUIRE(pass >= 0 && pass <= 2 && op >= 0 && op <= 4 && (es == 2 || es == 4), "bad op/pass/es");
   const int UE = 16 / es;                                        // elements per 16-byte unit in the emulated geometry
   const int OH = out_hw(op, H), OW = out_hw(op, W);
   const int inC = pass == 1 ? pad8(Cout) : pad8(Cin);

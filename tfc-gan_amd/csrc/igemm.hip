@@ -303,6 +303,7 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         const bool ok = nok && a < d.GH && b < d.GW;
         float v = acc[mi][nt][j] * osc + bv;
         if (flags & TFC_EP_LEAKY) v = fmaxf(v, 0.2f * v);
+        if (flags & TFC_EP_RELU) v = fmaxf(v, 0.f);
         if (STAGED && !(flags & TFC_EP_TANH_NCHW)) {
           if (ok) { s1 += v; s2 += v * v; }
           *reinterpret_cast<bf16_t*>(smem + (ty * TFC_TILE_W + tx) * ROWP + ((wn * NT + nt) * 32 + r) * 2) = f32_to_bf16(v);
@@ -705,6 +706,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
           float v0 = acc[mi][nt][4 * q + 0] * osc + bq[q].x, v1 = acc[mi][nt][4 * q + 1] * osc + bq[q].y;
           float v2 = acc[mi][nt][4 * q + 2] * osc + bq[q].z, v3 = acc[mi][nt][4 * q + 3] * osc + bq[q].w;
           if (flags & TFC_EP_LEAKY) { v0 = fmaxf(v0, 0.2f * v0); v1 = fmaxf(v1, 0.2f * v1); v2 = fmaxf(v2, 0.2f * v2); v3 = fmaxf(v3, 0.2f * v3); }
+          if (flags & TFC_EP_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
           pk[q][0] = pack_bf16x2(v0, v1);
           pk[q][1] = pack_bf16x2(v2, v3);
         }

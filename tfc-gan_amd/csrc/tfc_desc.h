@@ -34,6 +34,7 @@
 #define TFC_EP_ACCUM 4        // out += result (skip-connection gradient accumulation)
 #define TFC_EP_TANH_NCHW 8    // final layer: tanh, store fp32 NCHW
 #define TFC_EP_LEAKY 16       // LeakyReLU(0.2) on the result (discriminator blocks: no normalisation between conv and activation)
+#define TFC_EP_RELU 32        // ReLU on the result (the VGG feature stack of the LPIPS term)
 
 struct TfcPlane {
   int dy0, dx0;               // halo origin relative to the tile origin, in plane coordinates

@@ -9,7 +9,8 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (DT_BF16, DT_F32, EP_ACCUM, EP_BIAS, EP_LEAKY, EP_STATS, EP_TANH_NCHW, OP_CONV, OP_CONVT, OP_PADCONV, OP_UPCONV, check)
+from ._lib import (DT_BF16, DT_F32, EP_ACCUM, EP_BIAS, EP_LEAKY, EP_RELU, EP_STATS, EP_TANH_NCHW, OP_CONV, OP_CONV3, OP_CONVT, OP_PADCONV, OP_UPCONV,
+                   check)
 
 
 def lib():
@@ -136,7 +137,7 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-OUT_HW = {OP_CONV: lambda h: h - 1, OP_PADCONV: lambda h: h, OP_CONVT: lambda h: 2 * h, OP_UPCONV: lambda h: 2 * h}
+OUT_HW = {OP_CONV: lambda h: h - 1, OP_PADCONV: lambda h: h, OP_CONVT: lambda h: 2 * h, OP_UPCONV: lambda h: 2 * h, OP_CONV3: lambda h: h}
 
 
 # ---- convolution family ---------------------------------------------------------------------------------------
