@@ -7,7 +7,7 @@
 One process per GPU; each rank trains on its own 32 synthetic 256x256 thermal/visible pairs already resident in HBM
 (weak scaling), gradients are all-reduced over RCCL.  A "step" = the full generator step + discriminator step of
 TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py:545-638 (without LPIPS / temperature head).  Rank 0 prints ONE
-JSON line.  `roofline` is measured live with hipEvents around the launches of the dominant kernel family (tfc_igemm_kernel, the
+JSON line.  `roofline` is measured live with hipEvents around the launches of the dominant kernel (tfc_igemm2_kernel, the persistent
 halo-staged implicit-GEMM convolution) in every 4th step of the timed region; `cpu_baseline` times the CPU oracle (torch fp32 restatement
 of the same step) on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -24,9 +24,23 @@ PER_GPU_BATCH = 32
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(sample_n=8, steps=4):
-    """the oracle's TrainStep on the host cores: one untimed step (allocator / thread-pool warm-up) at N=1, one timed at N=sample_n.
-    Threads: the box's CPU share for one GPU is 16 cores (more torch threads than that only oversubscribe)."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(budget_s=14.0):
+    """The oracle's TrainStep (torch fp32 restatement of the same step, LPIPS / temperature head excluded as BASELINE.md section 3 defines it)
+    on the host cores of this box. BASELINE.md section 3 asks for N=4 and N=32 with >= 5 warm-up + >= 20 timed steps; at ~3 images/s that is
+    several minutes of CPU time, and this leg is bounded to ~30 s so that the default run still finishes in a few minutes: N=4 gets 2 warm-up
+    steps and then as many timed steps as fit in `budget_s` (at least 5); N=32 (the metric's batch) gets ONE timed step after that warm-up.
+    `value` is the N=32 figure. Threads: the box's CPU share for one GPU is 16 cores (more torch threads than that only oversubscribe)."""
     import torch
     from oracle import tfcgan_oracle as O
     cores = min(os.cpu_count() or 1, 16)
@@ -37,25 +51,33 @@ def cpu_baseline(sample_n=8, steps=4):
     D.apply(O.weights_init_normal)
     ts = O.TrainStep(G, D)
     neg = list(range(1, 16)) + [0]
-    A, B = O.synthetic_pairs(1, seed=1)
-    ts.step(A, B, neg)
-    A, B = O.synthetic_pairs(sample_n, seed=2)
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    A, B = O.synthetic_pairs(4, seed=2)
+    for _ in range(2):
         ts.step(A, B, neg)
-    dt = time.perf_counter() - t0
-    return {"value": sample_n * steps / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} full PATCH-16 steps (G step + D step, triplet16 + patch-FFT) on {sample_n} synthetic 256x256 pairs each, "
-                      f"torch fp32, {cores} threads, {dt:.1f} s"}
+    n4, t0 = 0, time.perf_counter()
+    while n4 < 5 or time.perf_counter() - t0 < budget_s:
+        ts.step(A, B, neg)
+        n4 += 1
+    dt4 = time.perf_counter() - t0
+    A, B = O.synthetic_pairs(32, seed=3)
+    t0 = time.perf_counter()
+    ts.step(A, B, neg)
+    dt32 = time.perf_counter() - t0
+    return {"value": 32 / dt32, "unit": "images/sec", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "n4_images_per_sec": 4 * n4 / dt4,
+            "sample": f"full PATCH-16 steps (G step + D step, triplet16 + patch-FFT, Adam; torch fp32, {cores} threads on {_cpu_model()}): "
+                      f"batch 4: 2 warm-up + {n4} timed steps in {dt4:.1f} s; batch 32 (value): 1 timed step in {dt32:.1f} s"}
 
 
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # written by scripts/pmc_traffic.py from the two --pmc passes of THIS command
+DOMINANT_KERNEL = "tfc_igemm2_kernel"
 PROF_EVERY = 4        # instrument every 4th timed step with hipEvents (see main)
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of THIS command (FETCH_SIZE and WRITE_SIZE collected in separate
-    runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- profiles/r01_pmc_traffic.json, or None if absent"""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- profiles/<PMC_TRAFFIC_FILE>, or None if absent"""
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -92,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lpips", action="store_true", help="include the LPIPS term (P16:598) in the timed step (seeded-random VGG16 weights)")
     ap.add_argument("--config", choices=["patch16", "glo16"], default="patch16",
                     help="patch16 = BASELINE.json configs[1] (the metric's configuration); glo16 = configs[2] (TFCGAN_multigpu_globalFFT_16P.py: "
                          "whole-image FFT loss instead of the 16 patch FFTs)")
@@ -129,13 +152,25 @@ def main():
     A, B = T.synthetic_pairs(args.batch, seed=1234 + rank)      # the product's own recipe: oracle/ is used by the checker legs only
     A, B = A.to(dev), B.to(dev)
 
+    extra = None
+    crit = None
+
+    def make_lpips():
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                       # "seeded-random weights" -- stated in config.workload instead
+            return T.LPIPS(net_type="vgg", version="0.1").to(dev)
+    if args.lpips:
+        crit = make_lpips()
+        extra = crit.as_extra_loss(0.5)
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ts.step(A, B)
+        ts.step(A, B, extra_loss_G=extra)
     barrier()
     # The roofline object is measured live, inside the timed region, with hipEvent pairs around the MFMA kernel launches on the launch
     # stream. An event pair costs ~2.3 us of stream time (A/B in scripts/ab_prof.py: 0.45 ms per fully instrumented step, 3.5 %), so
@@ -143,12 +178,19 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         T.ops.prof_enable(i % PROF_EVERY == 0)
-        out = ts.step(A, B)
+        out = ts.step(A, B, extra_loss_G=extra)
     barrier()
     elapsed = time.perf_counter() - t0
     T.ops.prof_enable(False)
+    recs = T.ops.prof_records(16384)
     ig_ms, ig_flop, ig_n = T.ops.prof_collect(0)
     wg_ms, wg_flop, wg_n = T.ops.prof_collect(1)
+    # the dominant kernel proper: class-0 calls that dispatch tfc_igemm2_kernel (bf16, whole 64-byte channel chunks, NHWC output); the rest of
+    # class 0 (first-layer tfc_conv_c8_kernel, the two 3-channel heads) is reported beside it
+    p8 = lambda c: (c + 7) // 8 * 8  # noqa: E731
+    dom = [r for r in recs if r["kclass"] == 0 and (p8(r["Cin"]) * 2) % 64 == 0 and (p8(r["Cout"]) * 2) % 64 == 0]
+    dom_ms, dom_flop = sum(r["ms"] for r in dom), sum(r["flop"] for r in dom)
+    dom_launches = sum(4 if (r["op"] in (T.ops.OP_CONVT, T.ops.OP_UPCONV) and r["pass"] == 0) else 1 for r in dom)
     loss_g, loss_d = float(out["loss_G"]), float(out["loss_D"])
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -158,7 +200,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.batch * world * args.steps / elapsed
-        achieved = (ig_flop / 1e12) / (ig_ms / 1e3) if ig_ms > 0 else 0.0
+        achieved = (dom_flop / 1e12) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         nprof = len(range(0, args.steps, PROF_EVERY))                       # timed steps that carried the hipEvent instrumentation
         step_s = elapsed / args.steps
         line = {
@@ -166,21 +208,41 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("PATCH-16 256x256 bf16, batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
-                                    "G step + D step, 16-patch triplet + patch-FFT loss, Adam") if args.config == "patch16" else
-                                   ("GLO-16 (TFCGAN_multigpu_globalFFT_16P.py) 256x256 bf16, batch 32 per GPU (BASELINE.json configs[2]): "
-                                    "G step + D step, 16-patch triplet + whole-image FFT loss, Adam"),
+            "config": {"workload": (("PATCH-16 256x256 bf16, batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
+                                     "G step + D step, 16-patch triplet + patch-FFT loss, Adam") if args.config == "patch16" else
+                                    ("GLO-16 (TFCGAN_multigpu_globalFFT_16P.py) 256x256 bf16, batch 32 per GPU (BASELINE.json configs[2]): "
+                                     "G step + D step, 16-patch triplet + whole-image FFT loss, Adam")) +
+                                   (" + 0.5 * LPIPS(fake_B, real_B) (P16:598, seeded-random VGG16 weights: same work, not the published metric)" if args.lpips else
+                                    " (step as BASELINE.md section 3 defines it: LPIPS and the temperature head excluded)"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_image": T.TrainStep.STEP_GFLOP},
-            "roofline": {"bound": "mfma", "kernel": "tfc_igemm_kernel (halo-staged implicit-GEMM conv: fwd/dgrad/convT/upconv)",
+            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (persistent halo-staged implicit-GEMM conv: fwd / dgrad / convT / upconv, bf16 MFMA 32x32x16)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("tfc_igemm_kernel"), "traffic_unit": "HBM bytes per launch (PMC)", "launches": ig_n, "avg_launch_ms": ig_ms / max(ig_n, 1),
-                         "instrumented_steps": nprof, "share_of_step_time": (ig_ms / 1e3 / nprof) / step_s,
+                         "traffic": pmc_traffic(DOMINANT_KERNEL), "traffic_unit": "HBM bytes per launch (PMC)", "launches": dom_launches,
+                         "avg_launch_ms": dom_ms / max(dom_launches, 1), "algorithmic_gflop_per_launch": dom_flop / 1e9 / max(dom_launches, 1),
+                         "instrumented_steps": nprof, "share_of_step_time": (dom_ms / 1e3 / nprof) / step_s,
+                         "whole_conv_class": {"kernels": "tfc_igemm2_kernel + tfc_conv_c8_kernel + 3-channel head kernels", "achieved": (ig_flop / 1e12) / (ig_ms / 1e3) if ig_ms > 0 else 0.0,
+                                              "unit": "TFLOP/s", "calls": ig_n, "share_of_step_time": (ig_ms / 1e3 / nprof) / step_s},
                          "second_kernel": {"kernel": "tfc_wgrad_kernel", "achieved": (wg_flop / 1e12) / (wg_ms / 1e3) if wg_ms > 0 else 0.0,
                                            "unit": "TFLOP/s", "launches": wg_n, "share_of_step_time": (wg_ms / 1e3 / nprof) / step_s}},
             "whole_step_tflops": T.TrainStep.STEP_GFLOP * value / 1e3,
             "final_losses": {"loss_G": loss_g, "loss_D": loss_d},
         }
+        if world == 1 and not args.lpips and not args.no_cpu_baseline:
+            # the reference's full loss_G also carries 0.5 * LPIPS (P16:598, :607): the same step with that term, timed right after
+            crit = make_lpips()
+            term = crit.as_extra_loss(0.5)
+            for _ in range(2):
+                ts.step(A, B, extra_loss_G=term)
+            torch.cuda.synchronize()
+            k2 = max(5, args.steps // 2)
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                ts.step(A, B, extra_loss_G=term)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            line["with_lpips"] = {"value": args.batch * k2 / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
+                                  "note": "same step + 0.5 * LPIPS(fake_B, real_B): VGG16 forward x2 + backward w.r.t. fake_B, seeded-random weights"}
         if world == 1 and not args.no_cpu_baseline:
             line["generator_l1_vs_oracle"] = generator_l1(dev)
             line["cpu_baseline"] = cpu_baseline()

@@ -184,6 +184,21 @@ int tfc_morph_grad_bwd(void* stream, const float* gout, const uint8_t* arg, floa
 int tfc_row_triplet_grad(void* stream, const float* anchor, const float* positive, const float* negative, long long rows, int W, float margin,
                          float gscale, float* loss, float* danchor);
 
+/* ---- input pipeline: ImageDataset.__getitem__, TFC-GAN-FFT/datasets_temp.py:38-123 --------------------------
+ * A decoded file is one RGB uint8 image [H][W][3] with the visible image A in columns [0, xsplit) and the thermal image B in [xsplit, W),
+ * xsplit = round-half-even(W / 2) as Image.crop((0, 0, w / 2, h)) does (:54-55). Each half is resized to out x out with PIL's BICUBIC
+ * resampler (:63-66; restated bit-exactly: antialiased separable convolution, 22-bit fixed-point taps, uint8 after each pass), then
+ * ToTensor + Normalize(0.5, 0.5) (P16:479-482) -> fp32 NCHW, and T_B = linspace(24, 38, 256)[B red channel] (:41-42, :69-70).
+ * The plan (tap tables of one file geometry) is built on the host and uploaded by the caller; all files of a batch share (H, W). */
+size_t tfc_resize_plan_bytes(int H, int W, int out);
+int tfc_resize_plan_build(int H, int W, int out, void* plan_host);
+size_t tfc_pair_resize_ws_bytes(int N, int H, int out);
+/* src: device uint8, image n at src + n * img_stride, rows row_stride bytes apart. plan_host / plan_dev: the same plan bytes on the host
+ * (header) and on the device (tables). A, B: fp32 [N][3][out][out]; TB (nullable): fp32 [N][out][out]; A8 / B8 (nullable): the resized
+ * uint8 images [N][out][out][3] (what PIL's resize returns, for callers that keep 8-bit copies). */
+int tfc_pair_resize_normalize(void* stream, const uint8_t* src, long long img_stride, int row_stride, int N, const void* plan_host,
+                              const void* plan_dev, void* ws, const float* lut256, float* A, float* B, float* TB, uint8_t* A8, uint8_t* B8);
+
 /* ---- LPIPS term of loss_G: criterion_lpips = lpips.LPIPS(net_type='vgg', version='0.1'), P16:70-73, used at
  * P16:598 inside loss_G. lpips_pytorch is a pip dependency that is absent from the reference tree; its published algorithm is restated
  * (PARITY UNPINNED): z-score the inputs, VGG16 features at relu1_2 / 2_2 / 3_3 / 4_3 / 5_3 (3x3 convolutions = TFC_OP_CONV3 with

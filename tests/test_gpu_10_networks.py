@@ -474,7 +474,9 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
         check(f"{name} norm/relu fwd", y_e, y.detach(), FWD, 0)
         g_cat = _nchw(dbg[f"{name}.g_out"])
         gw, gx = torch.autograd.grad(y, [w, x], g_cat[:, :cout])
-        check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gw, BWD, 1)
+        # up1's weight gradient sums only 16 pixels (4x4 input, N=1): the 1-ulp rounding differences of its bf16 dy (which follow the
+        # atomics order of the InstanceNorm statistics, so they move from run to run) are amplified ~4x by cancellation: 0.5..1.1e-2 observed
+        check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gw, 2 * BWD if name == "up1" else BWD, 1)
         check(f"{name} dgrad", _nchw(dbg[f"{name}.g_in"]), O._bf(gx), BWD, 1)
         h_in = cat.t.float().cpu().permute(0, 3, 1, 2).contiguous()   # whole concat buffer = next input
     # ---- head: upsample + pad + conv + tanh (weights of collapsed taps are summed in fp32 and rounded ONCE: compare in that arithmetic) ----

@@ -242,3 +242,38 @@ def test_profiling_state_is_per_thread():
     t.join()
     assert seen == {"n": 0, "rc": 0}
     assert lib.tfc_prof_enable(0) == 0
+
+
+def test_lpips_local_weight_files(tmp_path):
+    """LPIPS weights come from caller-supplied local files only (weights-only loader): torchvision's `features.N.*` layout plus the original
+    `lin{i}.model.1.weight` heads, or this class's own state_dict; anything partial is refused"""
+    import warnings
+    from tfc_gan_amd import lpips as L
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        src = T.LPIPS(seed=7)
+    assert any("seeded-random" in str(x.message) for x in w) and not src.pretrained
+    assert L.CONV_INDEX == (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+    vgg = {f"features.{k}.{n}": getattr(src.net.layers[k], n).detach().clone() for k in L.CONV_INDEX for n in ("weight", "bias")}
+    vgg["classifier.0.weight"] = torch.zeros(2, 2)                                # ignored, as torchvision's checkpoint carries it
+    lin = {f"lin{i}.model.1.weight": seq[1].weight.detach().clone() for i, seq in enumerate(src.lin)}
+    torch.save(vgg, tmp_path / "vgg16.pth")
+    torch.save(lin, tmp_path / "lin.pth")
+    torch.save(src.state_dict(), tmp_path / "own.pth")
+    a = T.LPIPS(weights=[tmp_path / "vgg16.pth", tmp_path / "lin.pth"], seed=1)
+    b = T.LPIPS(weights=str(tmp_path / "own.pth"), seed=2)
+    assert a.pretrained and b.pretrained
+    for k, v in src.state_dict().items():
+        assert torch.equal(a.state_dict()[k], v) and torch.equal(b.state_dict()[k], v)
+    assert all(not p.requires_grad for p in a.parameters())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        half = T.LPIPS(seed=1).load_pretrained(tmp_path / "lin.pth")              # heads only: accepted, but not "pretrained"
+        assert not half.pretrained
+        torch.save({k: v for k, v in list(vgg.items())[:6]}, tmp_path / "partial.pth")
+        with pytest.raises(T.TfcError):
+            T.LPIPS(weights=str(tmp_path / "partial.pth"))
+        with pytest.raises(T.TfcError):
+            T.LPIPS(net_type="alex")
+        with pytest.raises(T.TfcError):
+            T.LPIPS()(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))        # CPU tensors: no fallback

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libtfcgan_hip.so")
-SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "losses.hip", "stn.hip", "lpips.hip", "probe.hip"]
+SOURCES = ["api.hip", "igemm.hip", "elementwise.hip", "losses.hip", "stn.hip", "lpips.hip", "input.hip", "probe.hip"]
 HEADERS = ["common.h", "tfc_desc.h", "pack_math.h"]
 PUBLIC_HEADER = os.path.join(_ROOT, "include", "tfc_gan.h")
 
@@ -94,6 +94,10 @@ PROTOTYPES = {
     "tfc_morph_grad_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
     "tfc_morph_grad_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
     "tfc_row_triplet_grad": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _vp, _vp]),
+    "tfc_resize_plan_bytes": (_sz, [_i, _i, _i]),
+    "tfc_resize_plan_build": (_i, [_i, _i, _i, _vp]),
+    "tfc_pair_resize_ws_bytes": (_sz, [_i, _i, _i]),
+    "tfc_pair_resize_normalize": (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tfc_lpips_input_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "tfc_lpips_input_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i]),
     "tfc_maxpool2_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i]),

@@ -764,6 +764,102 @@ extern "C" int tfc_row_triplet_grad(void* stream, const float* anchor, const flo
   CHECK_HIP(tfc_launch_row_triplet_grad(anchor, positive, negative, rows, W, margin, 1e-6f, gscale, loss, danchor, (hipStream_t)stream), "tfc_row_triplet_grad");
   return 0;
 }
+// ---- input pipeline (input.hip) ---------------------------------------------------------------------------------------------------
+hipError_t tfc_launch_pair_resize(const uint8_t* src, long long img_stride, int row_stride, int N, const TfcResizePlan& p, const int* plan,
+                                  uint8_t* tmp, const float* lut, float* A, float* B, float* TB, uint8_t* A8, uint8_t* B8, hipStream_t st);
+namespace {
+// Pillow's bicubic kernel (a = -0.5) and coefficient precomputation (src/libImaging/Resample.c: bicubic_filter, precompute_coeffs,
+// normalize_coeffs_8bpc), restated: the SAME double arithmetic in the same order, so the quantised taps are identical to PIL's.
+double pil_bicubic(double x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+int pil_ksize(int in_size, int out_size) {
+  double fs = (double)in_size / out_size;
+  if (fs < 1.0) fs = 1.0;
+  return (int)ceil(2.0 * fs) * 2 + 1;
+}
+// bounds[out][2], coef[out][ksize]
+void pil_coeffs(int in_size, int out_size, int ksize, int* bounds, int* coef) {
+  const double scale = (double)in_size / out_size;
+  double filterscale = scale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 2.0 * filterscale, ss = 1.0 / filterscale;
+  std::vector<double> k(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = 0.0 + (xx + 0.5) * scale;
+    double ww = 0.0;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < xmax; ++x) {
+      const double w = pil_bicubic((x + xmin - center + 0.5) * ss);
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) k[x] /= ww;
+    for (int x = 0; x < ksize; ++x) {
+      const double v = x < xmax ? k[x] : 0.0;
+      coef[xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
+    }
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+  }
+}
+int pil_round_half_even(int w) {                                   // Image.crop rounds its float box with Python's round(): w / 2 for odd w
+  if (w % 2 == 0) return w / 2;
+  const int k = w / 2;                                             // w / 2 = k + 0.5
+  return (k % 2 == 0) ? k : k + 1;
+}
+size_t resize_plan_ints(int H, int W, int out) {
+  const int xs = pil_round_half_even(W);
+  const int kA = pil_ksize(xs, out), kB = pil_ksize(W - xs, out), kV = pil_ksize(H, out);
+  return (sizeof(TfcResizePlan) + 3) / 4 + (size_t)out * (6 + kA + kB + kV);
+}
+}  // namespace
+
+extern "C" size_t tfc_resize_plan_bytes(int H, int W, int out) { return (H > 0 && W > 1 && out > 0) ? 4 * resize_plan_ints(H, W, out) : 0; }
+extern "C" int tfc_resize_plan_build(int H, int W, int out, void* plan_host) {
+  REQUIRE(H > 0 && W > 1 && out > 0 && plan_host, "bad args");
+  REQUIRE((long long)H * W < (1 << 28), "image too large");
+  TfcResizePlan p;
+  memset(&p, 0, sizeof p);
+  p.out = out; p.H = H; p.W = W; p.xsplit = pil_round_half_even(W);
+  int* base = (int*)plan_host;
+  int off = (int)((sizeof(TfcResizePlan) + 3) / 4);
+  TfcResizeAxis* axes[3] = {&p.hA, &p.hB, &p.v};
+  const int sizes[3] = {p.xsplit, W - p.xsplit, H};
+  for (int i = 0; i < 3; ++i) {
+    TfcResizeAxis& a = *axes[i];
+    a.in_size = sizes[i];
+    a.ksize = pil_ksize(sizes[i], out);
+    a.bounds_off = off; off += 2 * out;
+    a.coef_off = off; off += a.ksize * out;
+    pil_coeffs(sizes[i], out, a.ksize, base + a.bounds_off, base + a.coef_off);
+  }
+  memcpy(plan_host, &p, sizeof p);
+  return 0;
+}
+extern "C" size_t tfc_pair_resize_ws_bytes(int N, int H, int out) { return (N > 0 && H > 0 && out > 0) ? (size_t)N * 2 * H * out * 3 : 0; }
+extern "C" int tfc_pair_resize_normalize(void* stream, const uint8_t* src, long long img_stride, int row_stride, int N, const void* plan_host,
+                                         const void* plan_dev, void* ws, const float* lut256, float* A, float* B, float* TB, uint8_t* A8, uint8_t* B8) {
+  REQUIRE(src && plan_host && plan_dev && ws && A && B && N > 0, "bad args");
+  REQUIRE(TB == nullptr || lut256 != nullptr, "T_B needs the 256-entry temperature table");
+  TfcResizePlan p;
+  memcpy(&p, plan_host, sizeof p);
+  REQUIRE(p.out > 0 && p.H > 0 && p.W > 1 && p.xsplit > 0 && p.xsplit < p.W, "corrupt plan header");
+  REQUIRE(row_stride >= 3 * p.W && img_stride >= (long long)row_stride * p.H, "strides smaller than the %d x %d RGB image of the plan", p.W, p.H);
+  CHECK_HIP(tfc_launch_pair_resize(src, img_stride, row_stride, N, p, (const int*)plan_dev, (uint8_t*)ws, lut256, A, B, TB, A8, B8, (hipStream_t)stream),
+            "tfc_pair_resize_normalize");
+  return 0;
+}
+
 // ---- LPIPS term (lpips.hip) ------------------------------------------------------------------------------------------------------
 hipError_t tfc_launch_lpips_input(int dt, const float* x, const float* shift, const float* scale, void* out, int N, int C, long long HW, int pitch, hipStream_t st);
 hipError_t tfc_launch_lpips_input_bwd(int dt, const void* g, const float* scale, float* dx, int N, int C, long long HW, int pitch, float alpha, int accumulate, hipStream_t st);

@@ -86,4 +86,10 @@ struct ActParams {
 extern thread_local int g_tfc_force_cfg;          // test hook (tfc_debug_set_igemm_config): -1 = heuristic tile choice
 extern thread_local long long g_tfc_launch_count; // kernel launches issued by the conv-class launchers on this thread (profiling join key)
 #define TFC_LAUNCH(...) do { ++g_tfc_launch_count; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+// ---- input pipeline (input.hip): resampling plan of one (H, W) file geometry -> 2 x (out x out). The plan buffer starts with this header,
+// followed by the int tables the offsets (in ints from the start of the buffer) point at: bounds[out][2] = {first source index, tap count},
+// coef[out][ksize] = taps in 22-bit fixed point.
+struct TfcResizeAxis { int ksize; int bounds_off; int coef_off; int in_size; };
+struct TfcResizePlan { TfcResizeAxis hA, hB, v; int out; int xsplit; int H; int W; };
 #endif
