@@ -277,3 +277,37 @@ def test_lpips_local_weight_files(tmp_path):
             T.LPIPS(net_type="alex")
         with pytest.raises(T.TfcError):
             T.LPIPS()(torch.zeros(1, 3, 32, 32), torch.zeros(1, 3, 32, 32))        # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("h,w", [(60, 200), (75, 131), (300, 1000)])
+def test_resize_plan_tables_reproduce_pil(h, w):
+    """tfc_resize_plan_build (host): its tap tables, evaluated with numpy integers exactly as the kernels do (22-bit taps, int32 accumulation
+    from 1 << 21, uint8 after each pass), reproduce PIL's Image.crop + Image.resize(BICUBIC) of both halves bit for bit"""
+    from PIL import Image
+    lib = _lib.load()
+    out = 64
+    n = lib.tfc_resize_plan_bytes(h, w, out)
+    buf = (ctypes.c_uint8 * n)()
+    _lib.check(lib.tfc_resize_plan_build(h, w, out, ctypes.cast(buf, ctypes.c_void_p)), "plan")
+    plan = np.frombuffer(bytes(buf), dtype=np.int32)
+    axes = [dict(ksize=plan[4 * i], b=plan[4 * i + 1], c=plan[4 * i + 2], n=plan[4 * i + 3]) for i in range(3)]
+    assert plan[12] == out and plan[14] == h and plan[15] == w
+    xs = int(plan[13])
+    assert xs == int(round(w / 2)) and axes[0]["n"] == xs and axes[1]["n"] == w - xs and axes[2]["n"] == h
+    img = np.random.default_rng(h).integers(0, 256, (h, w, 3)).astype(np.uint8)
+
+    def run(src, ax, axis):
+        src = np.moveaxis(src.astype(np.int64), axis, 0)
+        res = np.empty((out,) + src.shape[1:], dtype=np.uint8)
+        for o in range(out):
+            x0, cnt = plan[ax["b"] + 2 * o], plan[ax["b"] + 2 * o + 1]
+            k = plan[ax["c"] + o * ax["ksize"]: ax["c"] + o * ax["ksize"] + cnt].astype(np.int64)
+            acc = (1 << 21) + np.tensordot(k, src[x0:x0 + cnt], axes=(0, 0))
+            res[o] = np.clip(acc >> 22, 0, 255)
+        return np.moveaxis(res, 0, axis)
+    pil = Image.fromarray(img, "RGB")
+    for half, (x0, x1) in enumerate(((0, xs), (xs, w))):
+        got = run(run(img[:, x0:x1], axes[half], 1), axes[2], 0)
+        box = (0, 0, w / 2, h) if half == 0 else (w / 2, 0, w, h)
+        want = np.array(pil.crop(box).resize((out, out), Image.Resampling.BICUBIC))
+        assert np.array_equal(got, want)
