@@ -38,11 +38,11 @@ int tfc_nb32_padded(int nout);
 size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
-hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st);
+hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st, TfcWgradFin* fin);
 hipError_t tfc_launch_dgrad_rows4(const void* dy, int dy_pitch, int N, int H, int W, const float* w, int Cin, const float* oscale, int NC, float* dx, hipStream_t st);
 hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int W, const float* w, const float* bias, int Cout, float* out, hipStream_t st);
 bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
-                                   int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err);
+                                   int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err, TfcWgradFin* fin);
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
 hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st);
 hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st);
@@ -557,24 +557,28 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
   REQUIRE(op != TFC_OP_CONV3, "TFC_OP_CONV3 (frozen VGG features of the LPIPS term) has no weight-gradient pass");
   hipStream_t st = (hipStream_t)stream;
   WeightMap wm{};                                                // the accumulator part of ws is all-zero on entry (caller zeroes it ONCE) and again on exit
+  TfcWgradFin fin{dw, 0, 0, accumulate, false};
   {
     ProfScope prof(1, conv_flop(op, N, H, W, Cin, Cout), st, op, 2, N, H, W, Cin, Cout);
     bool fused = false;
     if ((op == TFC_OP_CONVT || op == TFC_OP_UPCONV) && dt == TFC_DT_BF16) {   // all four sub-pixel phases in one launch
       TfcGather d0;
       if (int e = build_desc(op, 2, 0, N, H, W, Cin, Cout, x_pitch, dy_pitch, &d0, &wm)) return e;   // wm: the weight layout map
+      fin.sn = wm.sn; fin.sc = wm.sc;
       hipError_t herr = hipSuccess;
       fused = tfc_launch_wgrad_phases_fused(op == TFC_OP_UPCONV, x, N, H, W, x_pitch, pad8(Cin), dy, dy_pitch, Cout, Cin,
-                                            (float*)((char*)ws + kWgradSlabBytes), ws, st, &herr);
+                                            (float*)((char*)ws + kWgradSlabBytes), ws, st, &herr, &fin);
       if (fused) CHECK_HIP(herr, "tfc_conv_wgrad (phase-fused)");
     }
-    for (int ph = 0; ph < num_phases(op, 2) && !fused; ++ph) {
+    const int nph = num_phases(op, 2);
+    for (int ph = 0; ph < nph && !fused; ++ph) {
       TfcGather d;
       if (int e = build_desc(op, 2, ph, N, H, W, Cin, Cout, x_pitch, dy_pitch, &d, &wm)) return e;
-      CHECK_HIP(tfc_launch_wgrad(dt, d, dy, x, (float*)((char*)ws + kWgradSlabBytes), ws, pad8(Cout), Cout, Cin, st), "tfc_conv_wgrad");
+      fin.sn = wm.sn; fin.sc = wm.sc;
+      CHECK_HIP(tfc_launch_wgrad(dt, d, dy, x, (float*)((char*)ws + kWgradSlabBytes), ws, pad8(Cout), Cout, Cin, st, nph == 1 ? &fin : nullptr), "tfc_conv_wgrad");
     }
   }
-  {
+  if (!fin.done) {
     ProfScope prof(2, 0.0, st, op, 3, N, H, W, Cin, Cout);     // class 2: the finish pass (layout + re-zero), no algorithmic FLOP of its own
     CHECK_HIP(tfc_launch_wgrad_finish((float*)((char*)ws + kWgradSlabBytes), dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_conv_wgrad finish");
   }

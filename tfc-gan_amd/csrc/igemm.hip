@@ -1994,6 +1994,74 @@ tfc_wgrad_finish_kernel(float* __restrict__ acc, float* __restrict__ grad, int N
   }
 }
 
+// Split-K reduction AND layout in one pass (kinds 0 and 2 with identity tap masks, i.e. the plain 4 x 4 convolution and the phase-fused
+// transposed convolution): the reduce kernel above adds into the fp32 accumulator [slot][n][c] (read-modify-write) and tfc_wgrad_finish_kernel
+// then reads that accumulator back, transposes it to the torch layout and re-zeroes it -- three passes over the gradient, 0.58 ms per step. Here a
+// workgroup owns the four filter taps (ky = g, kx = 0..3) of a 64-lane row group: its eight waves split the nsplit slabs, combine in LDS,
+// and wave 0 writes each (n, c) as ONE float4 = 16 contiguous bytes of the torch-layout gradient (both layouts keep the taps innermost).
+// The accumulator is never touched (it stays all-zero, as the other paths leave it).
+__global__ void __launch_bounds__(512)
+tfc_wgrad_reduce_fin_kernel(const float4* __restrict__ slab, float* __restrict__ grad, int kind, int T, int nsplit, int npairs, int ncbx,
+                            int Nn_real, int Cw_real, long long sn, long long sc, int accumulate) {
+  __shared__ float4 part[7][4][64];
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  int b = blockIdx.x;
+  const int g = b & 3; b >>= 2;
+  const int q = b & 3; b >>= 2;
+  int ni = 0;
+  if (kind == 0) { ni = b & 1; b >>= 1; }
+  const int pair = b;
+  const size_t blk_units = (size_t)4 * T * 4 * 64;
+  size_t row[4];
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx) {
+    int wv, a;
+    if (kind == 0) { wv = kx; a = g * 2 + ni; }                    // raster: tap = ti * 4 + wave, slab tile a = ti * 2 + ni
+    else {                                                       // phase-fused convT: ky = 1 - py + 2 jy, kx = 1 - px + 2 jx; wave = phase, a = (1-jy)*2 + (1-jx)
+      const int py = 1 - (g & 1), jy = g >> 1, px = 1 - (kx & 1), jx = kx >> 1;
+      wv = py * 2 + px; a = (1 - jy) * 2 + (1 - jx);
+    }
+    row[kx] = (size_t)pair * blk_units + ((size_t)wv * T + a) * 256 + q * 64 + lane;
+  }
+  float4 s[4];
+#pragma unroll
+  for (int kx = 0; kx < 4; ++kx) s[kx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+  for (int sp = k; sp < nsplit; sp += 8) {
+    const size_t o = (size_t)sp * npairs * blk_units;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const float4 v = slab[o + row[kx]];
+      s[kx].x += v.x; s[kx].y += v.y; s[kx].z += v.z; s[kx].w += v.w;
+    }
+  }
+  if (k > 0) {
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) part[k - 1][kx][lane] = s[kx];
+  }
+  __syncthreads();
+  if (k != 0) return;
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) { const float4 v = part[i][kx][lane]; s[kx].x += v.x; s[kx].y += v.y; s[kx].z += v.z; s[kx].w += v.w; }
+  const int cbx = pair % ncbx, nb = pair / ncbx;
+  const int c = cbx * 32 + (lane & 31);
+  const int n0 = (kind == 0 ? nb * 64 + ni * 32 : nb * 32) + 8 * q + 4 * (lane >> 5);
+  if (c >= Cw_real) return;
+  const float e0[4] = {s[0].x, s[1].x, s[2].x, s[3].x}, e1[4] = {s[0].y, s[1].y, s[2].y, s[3].y};
+  const float e2[4] = {s[0].z, s[1].z, s[2].z, s[3].z}, e3[4] = {s[0].w, s[1].w, s[2].w, s[3].w};
+  const float* ev[4] = {e0, e1, e2, e3};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (n0 + e >= Nn_real) continue;
+    float4* gp = reinterpret_cast<float4*>(grad + (long long)(n0 + e) * sn + (long long)c * sc + g * 4);
+    float4 o = make_float4(ev[e][0], ev[e][1], ev[e][2], ev[e][3]);
+    if (accumulate) { const float4 p0 = *gp; o.x += p0.x; o.y += p0.y; o.z += p0.z; o.w += p0.w; }
+    *gp = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host launchers (internal C++ API used by api.hip)
 // ---------------------------------------------------------------------------------------------------
@@ -2188,9 +2256,15 @@ hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const vo
                            : launch_igemm_t<float>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
 }
 
+// fin (nullable): torch-layout destination of the gradient. When the launch can reduce its slabs straight into it (tfc_wgrad_reduce_fin_kernel),
+// fin->done is set and the caller skips the finish pass.
+static bool tfc_fin_eligible(const TfcWgradFin* fin, int npairs, int sel) {
+  static const bool off = [] { const char* e = getenv("TFC_WGRAD_NO_FIN"); return e && atoi(e) != 0; }();   // A/B knob for profiling
+  return fin && fin->grad && !off && fin->sn % 16 == 0 && fin->sc % 16 == 0 && npairs * sel * 4 >= 256;     // enough workgroups to fill the chip
+}
 template <typename T>
 static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void* in, float* dwacc, float4* slab, int Nn_pad, int Nn_real,
-                                 int Cw_real, hipStream_t st) {
+                                 int Cw_real, hipStream_t st, TfcWgradFin* fin) {
   constexpr int ES = sizeof(T);
   const int nbw = (Nn_pad + 63) / 64, ncb = (d.Cin_pad + 31) / 32;
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
@@ -2235,14 +2309,20 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   if (raster) TFC_WG(4, true);
   else if (tpw <= 1) { tw = 1; TFC_WG(1, false); } else if (tpw == 2) { tw = 2; TFC_WG(2, false); } else if (tpw == 3) { tw = 3; TFC_WG(3, false); } else TFC_WG(4, false);
 #undef TFC_WG
-  if (slab)
+  bool ident = raster;                                           // identity tap masks: tap t IS filter slot t
+  for (int t = 0; t < 16 && ident; ++t) ident = d.plane[0].tap_mask[t] == (1 << t);
+  if (slab && ident && d.ph_n <= 1 && tfc_fin_eligible(fin, nbw * ncb, 8)) {
+    TFC_LAUNCH(tfc_wgrad_reduce_fin_kernel, dim3(nbw * ncb * 8 * 4), dim3(512), 0, st, slab, fin->grad, 0, 8, nsplit, nbw * ncb, ncb, Nn_real,
+               Cw_real, fin->sn, fin->sc, fin->accumulate);
+    fin->done = true;
+  } else if (slab)
     TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * (tw * 2) * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 0, tw * 2, nsplit,
                        nbw * ncb, ncb, Nn_real, Cw_real, -1);
   return hipGetLastError();
 }
 // transposed convolution / upsample conv, bf16: all four phases in one launch; false = not applicable (caller falls back to per-phase launches)
 bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW, int x_pitch, int Cin_pad, const void* dy, int dy_pitch, int Cout,
-                                   int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err) {
+                                   int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err, TfcWgradFin* fin) {
   if (g_tfc_force_cfg >= 0 && (g_tfc_force_cfg & 15) == 2) return false;   // tests: keep the per-phase kernels reachable
   const int Nn_pad = (Cout + 7) / 8 * 8;
   const int nbw = (Nn_pad + 31) / 32, ncb = (Cin_pad + 31) / 32;
@@ -2267,17 +2347,22 @@ bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW,
   } else {
     TFC_LAUNCH(tfc_wgradT_kernel<false>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
                        Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
-    TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 2, T, nsplit,
-                       nbw * ncb, ncb, Cout, Cin, -1);
+    if (tfc_fin_eligible(fin, nbw * ncb, 4)) {
+      TFC_LAUNCH(tfc_wgrad_reduce_fin_kernel, dim3(nbw * ncb * 4 * 4), dim3(512), 0, st, (const float4*)slab, fin->grad, 2, T, nsplit, nbw * ncb, ncb,
+                 Cout, Cin, fin->sn, fin->sc, fin->accumulate);
+      fin->done = true;
+    } else
+      TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 2, T, nsplit,
+                         nbw * ncb, ncb, Cout, Cin, -1);
   }
   *err = hipGetLastError();
   return true;
 }
 // slab: >= TFC_WGRAD_SLAB_BYTES of scratch for the split-K partials (bf16 path); nullptr = flush with fp32 atomics (fp32 parity mode)
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad,
-                            int Nn_real, int Cw_real, hipStream_t st) {
-  return dt == TFC_DT_BF16 ? launch_wgrad_t<bf16_t>(d, dO, in, dwacc, (float4*)slab, Nn_pad, Nn_real, Cw_real, st)
-                           : launch_wgrad_t<float>(d, dO, in, dwacc, nullptr, Nn_pad, Nn_real, Cw_real, st);
+                            int Nn_real, int Cw_real, hipStream_t st, TfcWgradFin* fin) {
+  return dt == TFC_DT_BF16 ? launch_wgrad_t<bf16_t>(d, dO, in, dwacc, (float4*)slab, Nn_pad, Nn_real, Cw_real, st, fin)
+                           : launch_wgrad_t<float>(d, dO, in, dwacc, nullptr, Nn_pad, Nn_real, Cw_real, st, nullptr);
 }
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
                                    int accumulate, hipStream_t st) {

@@ -87,6 +87,10 @@ extern thread_local int g_tfc_force_cfg;          // test hook (tfc_debug_set_ig
 extern thread_local long long g_tfc_launch_count; // kernel launches issued by the conv-class launchers on this thread (profiling join key)
 #define TFC_LAUNCH(...) do { ++g_tfc_launch_count; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+// torch-layout destination of a weight gradient, handed to the wgrad launchers: when a launch can reduce its split-K slabs straight into it
+// (tfc_wgrad_reduce_fin_kernel) it sets `done` and the caller skips the separate finish pass
+struct TfcWgradFin { float* grad; long long sn, sc; int accumulate; bool done; };
+
 // ---- input pipeline (input.hip): resampling plan of one (H, W) file geometry -> 2 x (out x out). The plan buffer starts with this header,
 // followed by the int tables the offsets (in ints from the start of the buffer) point at: bounds[out][2] = {first source index, tap count},
 // coef[out][ksize] = taps in 22-bit fixed point.
