@@ -42,6 +42,29 @@ if "cfg" in which:
             fl = 2.0 * N * (H - 1) ** 2 * Cin * Cout * 16
             print(f"H={H} {Cin}->{Cout} cfg {cfg}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
     lib.tfc_debug_set_igemm_config(-1)
+if "deep" in which:
+    # the small-plane layers of the generator: every tile configuration, forward (and dgrad for the transposed ones)
+    import time
+    lib = T._lib.load()
+    cases = [(ops.OP_CONV, 16, 512, 512), (ops.OP_CONV, 8, 512, 512), (ops.OP_CONVT, 4, 512, 512), (ops.OP_CONVT, 8, 1024, 512), (ops.OP_CONVT, 16, 1024, 256),
+             (ops.OP_CONVT, 32, 512, 128), (ops.OP_CONVT, 64, 256, 64), (ops.OP_CONV, 32, 256, 512)]
+    for op, H, Cin, Cout in cases:
+        x = rnd(N, H, H, Cin)
+        w = torch.randn((Cin, Cout, 4, 4) if op == ops.OP_CONVT else (Cout, Cin, 4, 4), device=DEV) * 0.03
+        oh = ops.OUT_HW[op](H)
+        y = ops.new_act(N, oh, oh, Cout, dt, DEV)
+        pk = ops.pack_weight(dt, op, 0, w, Cin, Cout)
+        for cfg in (-1, 0, 1, 2, 3):
+            lib.tfc_debug_set_igemm_config(cfg)
+            for _ in range(2):
+                ops.conv_fwd(dt, op, x, Cin, Cout, pk, y)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20):
+                ops.conv_fwd(dt, op, x, Cin, Cout, pk, y)
+            torch.cuda.synchronize(); dtm = (time.perf_counter() - t0) / 20
+            fl = 2.0 * N * (oh * oh if op == ops.OP_CONV else H * H * 4) * Cin * Cout * (16 if op == ops.OP_CONV else 4)
+            print(f"op {op} H={H} {Cin}->{Cout} cfg {cfg:2d}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
+    lib.tfc_debug_set_igemm_config(-1)
 if "stream" in which:
     import time
     def timeit(fn, reps=10):

@@ -2244,6 +2244,17 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
   if (fcfg >= 0 && fcfg != 15) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
   const int target = 512;
+  if constexpr (sizeof(T) == 2) {
+    // Few tiles, many output channels (the deep 16 x 16 ... 4 x 4 layers): the weight stream dominates. One 128-channel tile per workgroup with
+    // each wave owning 32 channels for all 128 pixels (no weight fragment is fetched by two waves) beats two 64-channel workgroups as soon as
+    // it still gives every CU a workgroup -- measured at batch 32: conv 16x16 512->512 70 -> 66 us, convT 16x16 1024->256 86 -> 67 us,
+    // convT 8x8 1024->512 84 -> 66 us, convT 4x4 512->512 44 -> 32 us, convT 32x32 512->128 100 -> 69 us (conv 8x8 512->512 would leave half
+    // the CUs idle: 50 -> 57 us, excluded; the four sub-pixel phases of a transposed convolution count as tiles).
+    static const bool old_rule = [] { const char* e = getenv("TFC_TILE_RULE_OLD"); return e && atoi(e) != 0; }();   // A/B knob for profiling
+    const int w128 = ntiles * (d.ph_n > 1 ? d.ph_n : 1) * ((nb + 3) / 4);
+    if (!old_rule && nb >= 4 && d.Cin_pad >= 64 && w128 >= tfc_num_cus() && w128 < 2048)   // (also 1-3 % ahead of <2,2,2,2> at 32 x 32 256->512; the two are equal beyond)
+      return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  }
   if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if (nb >= 2 && (ntiles * ((nb + 1) / 2) >= target || nb < 4)) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if (nb >= 4 && ntiles * nb < target / 2) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
