@@ -201,6 +201,17 @@ def test_first_layer_weights_stationary_kernel(N, H, W, Cin, Cout, with_bias):
                  oscale=torch.tensor([osc], device=DEV), flags=ops.EP_LEAKY if with_bias else 0)
     got = from_view(yv)
     assert (got - want).abs().max().item() <= tol(dt, want.abs().max().item())
+    # weight gradient of the same layer: the first-layer kernel (four taps of a filter row share one MFMA tile; split-K over <= 512 workgroups)
+    wq = q(w, dt).requires_grad_(True)
+    z = F.conv2d(x, wq, padding=1)
+    go = q(rnd(tuple(z.shape), 8), dt)
+    (gw,) = torch.autograd.grad(z, wq, go)
+    dw = torch.full((Cout, Cin, 4, 4), 3.0, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(dt, ops.OP_CONV, to_view(x, dt), to_view(go, dt), Cin, Cout, dw)
+    wtol = 2e-3 * gw.abs().max().item() + 1e-5
+    assert (dw.cpu() - gw).abs().max().item() <= wtol
+    ops.conv_wgrad(dt, ops.OP_CONV, to_view(x, dt), to_view(go, dt), Cin, Cout, dw, accumulate=True)
+    assert (dw.cpu() - 2 * gw).abs().max().item() <= 2 * wtol
 
 
 def test_patchgan_head_kernel_matches_padconv():

@@ -396,7 +396,7 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
     faithful, agrees end to end to better than ~1e-2 (scripts/debug_bf16_layers.py prints the growth). What CAN be tight is every layer on its
     own: each layer of the bf16 engine is fed to the oracle's bf16-STORAGE model of that layer (round to bf16 where the engine stores bf16, fp32 in
     between: oracle._RoundBoth / _RoundFwd / _RoundBwd) with the ENGINE's stored input, forward and backward: outputs, input gradients and weight
-    gradients of all 12 generator layers must agree to 1-ulp ties (rel-L2 <= 3e-3 forward, <= 1e-2 backward). A 10 % error in any bf16-only
+    gradients of all 12 generator layers must agree to 1-ulp ties (rel-L2 <= 5e-4 forward, <= 5e-3 backward). A 10 % error in any bf16-only
     kernel (first-layer conv, pooled activation, up-conv head, transposed-conv phases, fused wgrads) fails here by an order of magnitude."""
     T.set_compute_dtype(torch.bfloat16)
     torch.set_num_threads(16)
@@ -414,7 +414,7 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
     torch.cuda.synchronize()
     dbg = core.debug
     rb, rw, rg = O._RoundBoth.apply, O._RoundFwd.apply, O._RoundBwd.apply
-    FWD, BWD = 3e-3, 1e-2           # observed: forward <= 1.6e-3 (most layers 5e-5), backward <= 5.3e-3
+    FWD, BWD = 5e-4, 5e-3           # observed: forward <= 9.4e-5, backward <= 3.0e-3 (the dgrads that round an accumulated skip gradient)
     worst = [0.0, 0.0]
 
     def check(tag, got, want, tol, slot):
@@ -474,9 +474,8 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
         check(f"{name} norm/relu fwd", y_e, y.detach(), FWD, 0)
         g_cat = _nchw(dbg[f"{name}.g_out"])
         gw, gx = torch.autograd.grad(y, [w, x], g_cat[:, :cout])
-        # up1's weight gradient sums only 16 pixels (4x4 input, N=1): the 1-ulp rounding differences of its bf16 dy (which follow the
-        # atomics order of the InstanceNorm statistics, so they move from run to run) are amplified ~4x by cancellation: 0.5..1.1e-2 observed
-        check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gw, 2 * BWD if name == "up1" else BWD, 1)
+        # (until the blur kernels took the InstanceNorm sums from the STORED bf16 values, up1 -- 8 x 8 planes -- sat at 0.5..1.2e-2 here)
+        check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gw, BWD, 1)
         check(f"{name} dgrad", _nchw(dbg[f"{name}.g_in"]), O._bf(gx), BWD, 1)
         h_in = cat.t.float().cpu().permute(0, 3, 1, 2).contiguous()   # whole concat buffer = next input
     # ---- head: upsample + pad + conv + tanh (weights of collapsed taps are summed in fp32 and rounded ONCE: compare in that arithmetic) ----
@@ -492,7 +491,7 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
     gw, gb, gx = torch.autograd.grad(out, [w, b, x], g_fake)
     check("final wgrad", grads["final.2.weight"].cpu(), gw, BWD, 1)
     check("final bias grad", grads["final.2.bias"].cpu(), gb, BWD, 1)
-    check("final dgrad", _nchw(dbg["g_u5"]), O._bf(gx), 2.5e-2, 1)
+    check("final dgrad", _nchw(dbg["g_u5"]), O._bf(gx), 1e-2, 1)
     print("worst forward", worst[0], "worst backward", worst[1])
 
 

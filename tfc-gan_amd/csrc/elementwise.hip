@@ -84,11 +84,14 @@ tfc_act_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __re
 #pragma unroll
         for (int e = 0; e < UE; ++e) r[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? r[e] * p.drop_scale : 0.f;
       }
-      if (STATS_OUT) {
+      const uint4 pk = pack16<T>(r);
+      if (STATS_OUT) {                                             // InstanceNorm sums of the values actually STORED (the tensor the normaliser reads)
+        float rs[UE];
+        unpack16<T>(pk, rs);
 #pragma unroll
-        for (int e = 0; e < UE; ++e) { a1[e] += r[e]; a2[e] += r[e] * r[e]; }
+        for (int e = 0; e < UE; ++e) { a1[e] += rs[e]; a2[e] += rs[e] * rs[e]; }
       }
-      *reinterpret_cast<uint4*>(on + (size_t)pix * p.o_pitch + cv * UE) = pack16<T>(r);
+      *reinterpret_cast<uint4*>(on + (size_t)pix * p.o_pitch + cv * UE) = pk;
     }
   }
   if (STATS_OUT) {
@@ -620,9 +623,11 @@ tfc_blur1_kernel(const ActParams p, const T* __restrict__ src, int src_pitch, T*
                  wr03.w * ring[(ly + 3) % 5][e] + wr4 * ring[(ly + 4) % 5][e];
         if (xin && ty0 + ly < p.H) {
           const uint4 pk = pack16<T>(o);
-          if (STATS) {                                             // InstanceNorm sums of the fp32 result, as in the generic kernel
+          if (STATS) {                                             // InstanceNorm sums of the values actually STORED (bf16-rounded): the tensor
+            float os[UE];                                          // nn.InstanceNorm2d normalises; sums of the fp32 results differ from it by the
+            unpack16<T>(pk, os);                                   // rounding noise, which an 8 x 8 plane's backward amplifies to ~1e-2
 #pragma unroll
-            for (int e = 0; e < UE; ++e) { a1[e] += o[e]; a2[e] += o[e] * o[e]; }
+            for (int e = 0; e < UE; ++e) { a1[e] += os[e]; a2[e] += os[e] * os[e]; }
           }
           *reinterpret_cast<uint4*>(dn + (size_t)((ty0 + ly) * p.W + tx0 + lx) * dst_pitch + cvl * UE) = pk;
         }

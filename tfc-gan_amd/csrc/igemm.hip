@@ -1649,6 +1649,130 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Weight gradient of the FIRST layer (8 padded input channels, 4 x 4 raster taps, <= 64 outputs; bf16): G down1 3 -> 64 and D block 1 6 -> 64 at
+// 256 x 256. The generic kernel pads the 8 channels to a 32-wide MFMA tile per tap -- 4x the arithmetic, 127 us for 12.8 GFLOP. Here the four
+// taps of a filter ROW share one tile: the halo is kept at 16 bytes per pixel, so column (kx, c) of pixel x lives at  x * 16 + (kx * 8 + c) * 2
+// bytes -- a K(pixel)-strided matrix whose rows overlap (row pitch 16 B, row length 64 B), which the transposing LDS read takes as it is.
+// Wave w owns filter row ky = w: per k-step (16 pixels of a tile row) 2 A fragments (dO^T, 2 x 32 outputs), 1 B fragment, 2 MFMAs -- a quarter
+// of the generic kernel's MFMAs; the bound becomes the 266 MB dO stream. Split-K partials go to slabs [workgroup][ky][ni][q][lane] (32 KB per
+// workgroup), summed by tfc_wgrad_c8_reduce_kernel into the fp32 accumulator [slot][n][c] that tfc_wgrad_finish_kernel lays out.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tfc_wgrad_c8_kernel(const TfcGather d, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ in, float4* __restrict__ slab, int Nn_pad, int nsplit) {
+  constexpr int ROWB = 64;                                       // dO: 32 outputs x 2 bytes per LDS pixel row
+  constexpr int DO_BYTES = 2 * 128 * ROWB;
+  constexpr int HALO_BYTES = (TFC_MAX_HH * TFC_MAX_HW * 16 + 255) & ~255;
+  constexpr int BUF_BYTES = DO_BYTES + HALO_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TfcPlane& pd = d.plane[0];
+  const int sp = tfc_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+  f32x16_t acc[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[ni][j] = 0.f;
+
+  uint4 vdo[4], vha;
+  auto tile_load = [&](int tl) {
+    int t = tl;
+    const int txb = t % d.tiles_x; t /= d.tiles_x;
+    const int tyb = t % d.tiles_y;
+    const int img = t / d.tiles_y;
+    const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;                             // (ni * 128 + px) * 4 + g
+      const int g = idx & 3, px = (idx >> 2) & 127, ni = idx >> 9;
+      const int a = a0 + (px >> 4), b = b0 + (px & 15);
+      const int n0 = ni * 32 + g * 8;
+      vdo[i] = make_uint4(0, 0, 0, 0);
+      if (a < d.GH && b < d.GW && n0 < Nn_pad)
+        vdo[i] = load_stream16(dO + ((size_t)(img * d.OH + a + d.OOY) * d.OW + b + d.OOX) * d.out_pitch + n0);
+    }
+    vha = make_uint4(0, 0, 0, 0);
+    if (tid < pd.hh * pd.hw) {
+      const int hy = tid / pd.hw, hx = tid - hy * pd.hw;
+      const int y = a0 + pd.dy0 + hy, x = b0 + pd.dx0 + hx;
+      if (y >= 0 && y < d.IH && x >= 0 && x < d.IW) vha = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch);
+    }
+  };
+  auto tile_store = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(buf + (tid + i * 256) * 16) = vdo[i];
+    if (tid < TFC_MAX_HH * TFC_MAX_HW) *reinterpret_cast<uint4*>(buf + DO_BYTES + tid * 16) = vha;
+  };
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trA = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;        // dO: rows = pixels (64 B), columns = outputs
+  const int trB = (8 * hk + q) * 16 + cb16 * 32 + p * 8;          // halo: rows = pixels (16 B pitch, 64 B long: overlapping), columns = (kx, c)
+  auto tr16 = [&](const unsigned char* p0, int rowb4) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + rowb4));
+    uint4 r;
+    r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  };
+  auto compute = [&](const unsigned char* buf) {
+    const unsigned char* hrow = buf + DO_BYTES + wave * pd.hw * 16 + trB;   // halo row kt + ky, ky = wave
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+      const uint4 b = tr16(hrow + kt * pd.hw * 16, 4 * 16);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const uint4 a = tr16(buf + ni * 128 * ROWB + kt * 16 * ROWB + trA, 4 * ROWB);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[ni], 0, 0, 0);
+      }
+    }
+  };
+  int tl = sp, cur = 0;
+  if (tl < ntiles) { tile_load(tl); tile_store(smem); }
+  __syncthreads();
+  for (; tl < ntiles; tl += nsplit) {
+    const bool more = (tl + nsplit) < ntiles;
+    if (more) tile_load(tl + nsplit);
+    compute(smem + cur * BUF_BYTES);
+    if (more) tile_store(smem + (cur ^ 1) * BUF_BYTES);
+    __syncthreads();
+    cur ^= 1;
+  }
+  float4* ps = slab + ((size_t)sp * 4 + wave) * (2 * 4 * 64) + lane;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      ps[(ni * 4 + q4) * 64] = make_float4(acc[ni][4 * q4], acc[ni][4 * q4 + 1], acc[ni][4 * q4 + 2], acc[ni][4 * q4 + 3]);
+}
+// position = ((ky * 2 + ni) * 4 + q4) * 64 + lane of the 2048 float4 of a workgroup slab; block = 256 positions x one of `nchunk` slab ranges
+__global__ void __launch_bounds__(256)
+tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int nchunk, int Nn_real, int Cw_real) {
+  const int pos = (blockIdx.x & 7) * 256 + threadIdx.x;
+  const int ch = blockIdx.x >> 3;
+  const int per = (nsplit + nchunk - 1) / nchunk;
+  const int s0 = ch * per, s1 = (s0 + per) < nsplit ? (s0 + per) : nsplit;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int sp = s0; sp < s1; ++sp) {
+    const float4 v = slab[(size_t)sp * 2048 + pos];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int lane = pos & 63, q4 = (pos >> 6) & 3, ni = (pos >> 8) & 1, ky = pos >> 9;
+  const int col = lane & 31, kx = col >> 3, c = col & 7;
+  const int n0 = ni * 32 + 8 * q4 + 4 * (lane >> 5);
+  if (c >= Cw_real) return;
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n0 + e < Nn_real) atomicAdd(&acc[((size_t)(ky * 4 + kx) * Nn_real + n0 + e) * Cw_real + c], sv[e]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight packing: torch fp32 weight -> operand stream  wp[((gs*NB32 + nb)*64 + lane)] (16 bytes each)
 //   gs enumerates (chunk, plane, k-substep); lane = (rn, h); unit u = 2*s + h; tap = u / UPP; g = u % UPP;
 //   element e <-> channel c = chunk*CK + g*UE + e;  value = W[n*sn + c*sc + slot(tap)] * (*scale)
@@ -2314,6 +2438,19 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   const int tpw = (d.plane[0].ntaps + 3) / 4;                    // taps per wave (tap t belongs to wave t % 4)
   bool raster = (ES == 2) && d.plane[0].ntaps == 16;
   for (int t = 0; t < 16 && raster; ++t) raster = d.plane[0].tap_dy[t] == (t >> 2) && d.plane[0].tap_dx[t] == (t & 3);
+  if constexpr (ES == 2) {
+    static const bool c8_off = [] { const char* e = getenv("TFC_WGRAD_NO_C8"); return e && atoi(e) != 0; }();   // A/B knob for profiling
+    bool ident = raster;
+    for (int t = 0; t < 16 && ident; ++t) ident = d.plane[0].tap_mask[t] == (1 << t);
+    if (slab && ident && !c8_off && d.Cin_pad == 8 && d.in_pitch == 8 && Nn_pad <= 64 && d.ph_n <= 1 && d.SS == 1 && d.OS == 1 &&
+        d.plane[0].hh <= TFC_MAX_HH && d.plane[0].hw <= TFC_MAX_HW && (g_tfc_force_cfg < 0 || (g_tfc_force_cfg & 15) == 15)) {
+      const int ns = ntiles < 512 ? ntiles : 512;                 // 2 workgroups per CU, 32 KB of slab each
+      TFC_LAUNCH(tfc_wgrad_c8_kernel, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)dO, (const bf16_t*)in, slab, Nn_pad, ns);
+      const int nchunk = ns >= 16 ? 16 : 1;
+      TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(8 * nchunk), dim3(256), 0, st, slab, dwacc, ns, nchunk, Nn_real, Cw_real);
+      return hipGetLastError();
+    }
+  }
 #define TFC_WG(TPW_, R_) TFC_LAUNCH((tfc_wgrad_kernel<T, TPW_, R_>), grid, dim3(256), lds, st, d, (const T*)dO, (const T*)in, dwacc, slab, \
                                             Nn_pad, Nn_real, Cw_real, nbw, ncb, nsplit)
   int tw = 4;
