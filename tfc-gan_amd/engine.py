@@ -22,7 +22,7 @@ from .ops import DT_BF16
 
 class TrainStep:
     def __init__(self, generator, discriminator, lr=2e-4, b1=0.5, b2=0.999, eps=1e-8, compute_dtype=torch.bfloat16,
-                 fft_mode="patch", seed=0, bucket_bytes=16 << 20, lambda_gan=0.5, lambda_fft=0.01, lambda_trip=1.0):
+                 fft_mode="patch", seed=0, bucket_bytes=16 << 20, lambda_gan=0.5, lambda_fft=0.01, lambda_trip=1.0, d_bucket_bytes=4 << 20):
         dev = next(generator.parameters()).device
         if dev.type != "cuda":
             raise ops._lib.TfcError("TrainStep needs the modules on a CUDA/HIP device (no CPU fallback)")
@@ -49,7 +49,9 @@ class TrainStep:
         self.gm, self.gv = torch.zeros_like(self.gflat.data), torch.zeros_like(self.gflat.data)
         self.dm, self.dv = torch.zeros_like(self.dflat.data), torch.zeros_like(self.dflat.data)
         self.g_reduce = parallel.BucketReducer(self.gflat, bucket_bytes)
-        self.d_reduce = parallel.BucketReducer(self.dflat, bucket_bytes)
+        # the discriminator's 11 MB of gradients: its largest layer (model.9, 8.4 MB) is final first, so a 4 MiB cut lets that part of the exchange
+        # run under the rest of the D backward; only the last ~2.6 MB (model.6, .3, .0) are exposed
+        self.d_reduce = parallel.BucketReducer(self.dflat, min(bucket_bytes, d_bucket_bytes))
         self.G = nets.GeneratorCore(self.dt, generator.channels)
         self.G.set_params(self.gflat.views)
         self.D = nets.DiscriminatorCore(self.dt, discriminator.channels)
