@@ -190,7 +190,7 @@ def main():
     p8 = lambda c: (c + 7) // 8 * 8  # noqa: E731
     dom = [r for r in recs if r["kclass"] == 0 and (p8(r["Cin"]) * 2) % 64 == 0 and (p8(r["Cout"]) * 2) % 64 == 0]
     dom_ms, dom_flop = sum(r["ms"] for r in dom), sum(r["flop"] for r in dom)
-    dom_launches = sum(4 if (r["op"] in (T.ops.OP_CONVT, T.ops.OP_UPCONV) and r["pass"] == 0) else 1 for r in dom)
+    dom_launches = len(dom)                               # one launch per call: the four sub-pixel phases of a transposed convolution fold into one grid
     loss_g, loss_d = float(out["loss_G"]), float(out["loss_D"])
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
