@@ -427,7 +427,15 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   constexpr int P = TFC_LDS_P;
   constexpr int NSR = TapPat<PAT>::COLS * 2;
   constexpr int ROWS = TapPat<PAT>::ROWS;
-  constexpr int BD = (PAT == 6) ? TFC_BD2_PAT6 : TFC_BD2;           // weight-ring depth in k-substeps
+  // weight-ring depth in k-substeps. A wave has BD * NT one-KiB fragment loads in flight; the deep layers' operand streams (8-17 MB) miss the 4 MB
+  // L2 of an XCD, so their K loop ran at (fragments in flight) / (memory latency): 4 per ~500 ns = 230 cycles per k-substep instead of 64.
+  // One-fragment-per-substep tiles (NT == 1: the configurations those layers use) therefore keep 8 substeps in flight (32 VGPRs).
+#ifndef TFC_BD2_NT1
+#define TFC_BD2_NT1 8
+#endif
+  constexpr int BDW = (NT == 1) ? TFC_BD2_NT1 : TFC_BD2;
+  constexpr int BD = (PAT == 6) ? (NT == 1 ? 6 : TFC_BD2_PAT6) : (BDW <= ROWS * NSR ? BDW : ROWS * NSR);
+  static_assert(BD <= TFC_WPAD, "the packed stream carries TFC_WPAD slack k-substeps for the ring's read-ahead");
   static_assert((ROWS * NSR) % BD == 0, "register ring must realign every stage");
   constexpr int BN = 32 * NT * WN;
   constexpr int ROWP = BN * 2 + 16;                              // staged tile: bytes per pixel row (pitch = 4 banks mod 32)

@@ -23,7 +23,7 @@
 #define TFC_MAX_HW 19         // max halo cols (16 + 3)
 #define TFC_MAX_TAPS 16
 #define TFC_MAX_PLANES 4
-#define TFC_WPAD 8            // slack k-substeps at the end of a packed weight stream (prefetch distance headroom)
+#define TFC_WPAD 16           // slack k-substeps at the end of a packed weight stream (prefetch distance headroom)
 
 #define TFC_DT_BF16 0
 #define TFC_DT_F32 1
