@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 PER_GPU_BATCH = 32
 MFMA_BF16_PEAK_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3            # fp32 MFMA (v_mfma_f32_32x32x2_f32): 1/16 of the bf16 rate, same guide
 
 
 def _cpu_model():
@@ -114,6 +115,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16",
+                    help="bf16 = the benchmarked arithmetic (BASELINE.json); fp32 = the exact-fp32 parity mode (generator L1 vs oracle 1.9e-6), on the "
+                         "legacy one-tile-per-workgroup kernels at 1/16 of the MFMA rate -- reported so that its cost is a number, not a guess")
     ap.add_argument("--lpips", action="store_true", help="include the LPIPS term (P16:598) in the timed step (seeded-random VGG16 weights)")
     ap.add_argument("--config", choices=["patch16", "glo16"], default="patch16",
                     help="patch16 = BASELINE.json configs[1] (the metric's configuration); glo16 = configs[2] (TFCGAN_multigpu_globalFFT_16P.py: "
@@ -142,13 +146,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    T.set_compute_dtype(torch.bfloat16)
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    T.set_compute_dtype(cdt)
     torch.manual_seed(42)                                # reference: torch.manual_seed(42), P16:61
     G = T.GeneratorUNet((3, 256, 256)).to(dev)
     D = T.Discriminator1((3, 256, 256)).to(dev)
     G.apply(T.weights_init_normal)
     D.apply(T.weights_init_normal)
-    ts = T.TrainStep(G, D, compute_dtype=torch.bfloat16, fft_mode="patch" if args.config == "patch16" else "global")
+    ts = T.TrainStep(G, D, compute_dtype=cdt, fft_mode="patch" if args.config == "patch16" else "global")
     A, B = T.synthetic_pairs(args.batch, seed=1234 + rank)      # the product's own recipe: oracle/ is used by the checker legs only
     A, B = A.to(dev), B.to(dev)
 
@@ -188,7 +193,10 @@ def main():
     # the dominant kernel proper: class-0 calls that dispatch tfc_igemm2_kernel (bf16, whole 64-byte channel chunks, NHWC output); the rest of
     # class 0 (first-layer tfc_conv_c8_kernel, the two 3-channel heads) is reported beside it
     p8 = lambda c: (c + 7) // 8 * 8  # noqa: E731
-    dom = [r for r in recs if r["kclass"] == 0 and (p8(r["Cin"]) * 2) % 64 == 0 and (p8(r["Cout"]) * 2) % 64 == 0]
+    es = 2 if args.dtype == "bf16" else 4
+    dom = [r for r in recs if r["kclass"] == 0 and (p8(r["Cin"]) * es) % 64 == 0 and (p8(r["Cout"]) * es) % 64 == 0]
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    kname = DOMINANT_KERNEL if args.dtype == "bf16" else "tfc_igemm_kernel"
     dom_ms, dom_flop = sum(r["ms"] for r in dom), sum(r["flop"] for r in dom)
     dom_launches = len(dom)                               # one launch per call: the four sub-pixel phases of a transposed convolution fold into one grid
     loss_g, loss_d = float(out["loss_G"]), float(out["loss_D"])
@@ -207,18 +215,19 @@ def main():
             "metric": "training images/sec at 256x256 PATCH-16, 1/2/4/8 MI355X; gen L1 vs ref",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": (("PATCH-16 256x256 bf16, batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": (("PATCH-16 256x256 " + args.dtype + ", batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
                                      "G step + D step, 16-patch triplet + patch-FFT loss, Adam") if args.config == "patch16" else
-                                    ("GLO-16 (TFCGAN_multigpu_globalFFT_16P.py) 256x256 bf16, batch 32 per GPU (BASELINE.json configs[2]): "
+                                    ("GLO-16 (TFCGAN_multigpu_globalFFT_16P.py) 256x256 " + args.dtype + ", batch 32 per GPU (BASELINE.json configs[2]): "
                                      "G step + D step, 16-patch triplet + whole-image FFT loss, Adam")) +
                                    (" + 0.5 * LPIPS(fake_B, real_B) (P16:598, seeded-random VGG16 weights: same work, not the published metric)" if args.lpips else
                                     " (step as BASELINE.md section 3 defines it: LPIPS and the temperature head excluded)"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_image": T.TrainStep.STEP_GFLOP},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (persistent halo-staged implicit-GEMM conv: fwd / dgrad / convT / upconv, bf16 MFMA 32x32x16)",
-                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(DOMINANT_KERNEL), "traffic_unit": "HBM bytes per launch (PMC)", "launches": dom_launches,
+            "roofline": {"bound": "mfma", "kernel": kname + (" (persistent halo-staged implicit-GEMM conv: fwd / dgrad / convT / upconv, bf16 MFMA 32x32x16)" if args.dtype == "bf16"
+                                                             else " (one-tile-per-workgroup halo-staged implicit GEMM, fp32 MFMA 32x32x2: exact fp32 parity mode)"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": pmc_traffic(DOMINANT_KERNEL) if args.dtype == "bf16" else None, "traffic_unit": "HBM bytes per launch (PMC)", "launches": dom_launches,
                          "avg_launch_ms": dom_ms / max(dom_launches, 1), "algorithmic_gflop_per_launch": dom_flop / 1e9 / max(dom_launches, 1),
                          "instrumented_steps": nprof, "share_of_step_time": (dom_ms / 1e3 / nprof) / step_s,
                          "whole_conv_class": {"kernels": "tfc_igemm2_kernel + tfc_conv_c8_kernel + 3-channel head kernels", "achieved": (ig_flop / 1e12) / (ig_ms / 1e3) if ig_ms > 0 else 0.0,
@@ -228,7 +237,7 @@ def main():
             "whole_step_tflops": T.TrainStep.STEP_GFLOP * value / 1e3,
             "final_losses": {"loss_G": loss_g, "loss_D": loss_d},
         }
-        if world == 1 and not args.lpips and not args.no_cpu_baseline:
+        if world == 1 and not args.lpips and not args.no_cpu_baseline and args.dtype == "bf16":
             # the reference's full loss_G also carries 0.5 * LPIPS (P16:598, :607): the same step with that term, timed right after
             crit = make_lpips()
             term = crit.as_extra_loss(0.5)
