@@ -65,6 +65,26 @@ if "deep" in which:
             fl = 2.0 * N * (oh * oh if op == ops.OP_CONV else H * H * 4) * Cin * Cout * (16 if op == ops.OP_CONV else 4)
             print(f"op {op} H={H} {Cin}->{Cout} cfg {cfg:2d}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
     lib.tfc_debug_set_igemm_config(-1)
+if "wgt" in which:
+    # timed weight gradients of the three big conv layers and the transposed ones (hipEvents around 10 calls each)
+    shapes = [(ops.OP_CONV, 128, 64, 128), (ops.OP_CONV, 64, 128, 256), (ops.OP_CONV, 32, 256, 512), (ops.OP_CONV, 16, 512, 512),
+              (ops.OP_CONVT, 64, 256, 64), (ops.OP_CONVT, 32, 512, 128), (ops.OP_CONVT, 16, 1024, 256), (ops.OP_CONVT, 8, 1024, 512)]
+    ws = None
+    for op, H, Cin, Cout in shapes:
+        x = rnd(N, H, H, Cin)
+        oh = ops.OUT_HW[op](H)
+        gy = rnd(N, oh, oh, Cout)
+        dw = torch.empty((Cin, Cout, 4, 4) if op == ops.OP_CONVT else (Cout, Cin, 4, 4), device=DEV)
+        for _ in range(2):
+            ws = ops.conv_wgrad(dt, op, x, gy, Cin, Cout, dw, False, ws)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            ws = ops.conv_wgrad(dt, op, x, gy, Cin, Cout, dw, False, ws)
+        b.record(); torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 100
+        fl = 2.0 * N * (oh * oh * 16 if op == ops.OP_CONV else H * H * 4 * 4) * Cin * Cout
+        print(f"wgrad op {op} H={H} {Cin}->{Cout}: {us:7.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
 if "stream" in which:
     import time
     def timeit(fn, reps=10):

@@ -1457,6 +1457,9 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
 
   uint4 vdo[NDO], vha[NHA];
   auto tile_load = [&](int tl) {
+#ifdef TFC_ABL_WG_SAMETILE
+    tl = sp;                                                     // ablation: every load hits the workgroup's first (cache-hot) tile
+#endif
     int t = tl;
     const int txb = t % d.tiles_x; t /= d.tiles_x;
     const int tyb = t % d.tiles_y;
@@ -2029,6 +2032,161 @@ tfc_wgradT_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int
       ps[(a * 4 + q4) * 64] = make_float4(acc[a][4 * q4], acc[a][4 * q4 + 1], acc[a][4 * q4 + 2], acc[a][4 * q4 + 3]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient of the generator head (Upsample x2 -> ZeroPad -> Conv2d(128, C <= 8, 4); P16:150-157), bf16. tfc_wgradT_kernel<true> spends a
+// 32-row MFMA tile on the 3 (padded: 8) output channels of ONE sub-pixel phase per wave: 4.7 M MFMAs, 147 us, MFMA-bound on padding. Here the four
+// phases x 8 padded channels ARE the 32 rows (row = phase * 8 + oc): dy of a tile is staged as [input-grid pixel][py][px][oc8] = 64 bytes per
+// pixel, so the transposing read that the other wgrad kernels use yields the merged A fragment directly; wave w owns input channels 32w..32w+31
+// and slides the 3 x 3 source-offset window down the 10 x 18 x 128-channel halo (3 new B fragments + 1 A fragment per 9 MFMAs). A quarter of the
+// MFMAs and dy is read once instead of four times: the bound becomes the 134 MB x stream. Accumulators of (phase, offset) pairs a phase does
+// not have are ignored by the reduce pass (as for tfc_wgradT_kernel<true>).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tfc_wgrad_head_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, const bf16_t* __restrict__ dy, int dy_pitch, int nimg,
+                      float4* __restrict__ slab, int nsplit) {
+  constexpr int HH = TFC_TILE_H + 2, HW = TFC_TILE_W + 2;          // 10 x 18 halo of x, 128 channels = 256 B per pixel
+  constexpr int DY_BYTES = 128 * 64;                             // [pixel][py][px][oc8]
+  constexpr int HB = 256, ROWB = 64;
+  constexpr int NHA = (HH * HW * 16 + 255) / 256;                // 12 halo units per thread
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DY_BYTES + HH * HW * HB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int OH = 2 * IH, OW = 2 * IW;
+  const int tiles_y = (IH + TFC_TILE_H - 1) / TFC_TILE_H, tiles_x = (IW + TFC_TILE_W - 1) / TFC_TILE_W;
+  const int ntiles = nimg * tiles_y * tiles_x;
+  const int sp = tfc_xcd_remap(blockIdx.x, gridDim.x);
+  f32x16_t acc[9];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
+
+  auto tile_stage = [&](int tl) {                                 // global -> LDS (through registers, a few units at a time: 144 accumulator VGPRs are live)
+    int t = tl;
+    const int txb = t % tiles_x; t /= tiles_x;
+    const int tyb = t % tiles_y;
+    const int img = t / tiles_y;
+    const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;                             // pixel * 4 + phase
+      const int ph = idx & 3, pxl = idx >> 2;
+      const int a = a0 + (pxl >> 4), b = b0 + (pxl & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a < IH && b < IW) v = *reinterpret_cast<const uint4*>(dy + ((size_t)(img * OH + 2 * a + (ph >> 1)) * OW + 2 * b + (ph & 1)) * dy_pitch);
+      *reinterpret_cast<uint4*>(smem + idx * 16) = v;
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < NHA; i0 += 4) {
+      uint4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + (i0 + i) * 256;                    // pixel * 16 + unit
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (i0 + i < NHA && idx < HH * HW * 16) {
+          const int u = idx & 15, pix = idx >> 4;
+          const int hy = pix / HW, hx = pix - hy * HW;
+          const int y = a0 - 1 + hy, xx = b0 - 1 + hx;
+          if (y >= 0 && y < IH && xx >= 0 && xx < IW) v[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(img * IH + y) * IW + xx) * x_pitch + u * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + (i0 + i) * 256;
+        if (i0 + i < NHA && idx < HH * HW * 16) *reinterpret_cast<uint4*>(smem + DY_BYTES + idx * 16) = v[i];
+      }
+    }
+  };
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trA = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;
+  const int trB = (8 * hk + q) * HB + wave * 64 + cb16 * 32 + p * 8;
+  auto tr16 = [&](const unsigned char* p0, int rowb4) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + rowb4));
+    uint4 r;
+    r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  };
+  auto compute = [&]() {
+    const unsigned char* acol = smem + trA;
+    const unsigned char* hcol = smem + DY_BYTES + trB;
+    constexpr int rowb = HW * HB;
+    uint4 rw[3][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rw[r][c] = tr16(hcol + r * rowb + c * HB, 4 * HB);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rw[2][c] = tr16(hcol + (kt + 2) * rowb + c * HB, 4 * HB);
+      const bf16x8_t av = __builtin_bit_cast(bf16x8_t, tr16(acol + kt * 16 * ROWB, 4 * ROWB));
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          acc[r * 3 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, rw[r][c]), acc[r * 3 + c], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rw[r][c] = rw[r + 1][c];
+    }
+  };
+  for (int tl = sp; tl < ntiles; tl += nsplit) {
+    tile_stage(tl);
+    __syncthreads();
+    compute();
+    __syncthreads();
+  }
+  float4* ps = slab + ((size_t)sp * 4 + wave) * (9 * 4 * 64) + lane;
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      ps[(a * 4 + q4) * 64] = make_float4(acc[a][4 * q4], acc[a][4 * q4 + 1], acc[a][4 * q4 + 2], acc[a][4 * q4 + 3]);
+}
+// position = ((w * 9 + a) * 4 + q4) * 64 + lane of the 9216 float4 of a workgroup slab; block = 256 positions x one of `nchunk` slab ranges.
+// row (phase * 8 + oc) of offset a = ir * 3 + ic feeds every filter tap that collapses onto that offset in that phase.
+__global__ void __launch_bounds__(256)
+tfc_wgrad_head_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int nchunk, int Nn_real, int Cw_real) {
+  const int pos = (blockIdx.x % 36) * 256 + threadIdx.x;
+  const int ch = blockIdx.x / 36;
+  const int per = (nsplit + nchunk - 1) / nchunk;
+  const int s0 = ch * per, s1 = (s0 + per) < nsplit ? (s0 + per) : nsplit;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int sp = s0; sp < s1; ++sp) {
+    const float4 v = slab[(size_t)sp * 9216 + pos];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int lane = pos & 63, q4 = (pos >> 6) & 3, a = (pos >> 8) % 9, w = pos / 2304;
+  const int c = w * 32 + (lane & 31);
+  const int row0 = 8 * q4 + 4 * (lane >> 5);
+  const int ph = row0 >> 3, oc0 = row0 & 7;                       // the four rows of a float4 share their phase (row0 % 4 == 0)
+  if (c >= Cw_real) return;
+  const int wpy = ph >> 1, wpx = ph & 1, ir = a / 3, ic = a % 3;
+  int mask = 0;
+  if (ir < 2 + wpy && ic < 2 + wpx)
+    for (int ky = 0; ky < 4; ++ky)
+      for (int kx = 0; kx < 4; ++kx) {
+        const int sy = wpy ? (ky == 0 ? 0 : (ky == 3 ? 2 : 1)) : (ky >> 1);   // source row offset + 1 of filter row ky in this phase
+        const int sx = wpx ? (kx == 0 ? 0 : (kx == 3 ? 2 : 1)) : (kx >> 1);
+        if (sy == ir && sx == ic) mask |= 1 << (ky * 4 + kx);
+      }
+  const float sv[4] = {s.x, s.y, s.z, s.w};
+  for (int m = mask; m; m &= m - 1) {
+    const int slot = __ffs(m) - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (oc0 + e < Nn_real) atomicAdd(&acc[((size_t)slot * Nn_real + oc0 + e) * Cw_real + c], sv[e]);
+  }
+}
+
 // Split-K reduction of the weight-gradient slabs. fp32 atomics run at ~1.3 TB/s on this chip (they execute at the memory side) and a
 // one-round wgrad launch flushes the WHOLE chip's accumulator state (~67 MB): ~50 us of a ~130 us kernel. Instead every workgroup
 // stores its accumulators, in register order, with plain 16-byte stores (~6 TB/s): slab[workgroup = sp*npairs + pair][wave][tile a][q][lane]
@@ -2494,6 +2652,18 @@ bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW,
   const int lds = 4 * 128 * 64 + (TFC_TILE_H + 2) * (TFC_TILE_W + 2) * 64;
   const dim3 grid(nbw * ncb * nsplit);
   TfcPlane none{};
+  static const bool head_off = [] { const char* e = getenv("TFC_WGRAD_NO_HEAD"); return e && atoi(e) != 0; }();   // A/B knob for profiling
+  if (up && !head_off && Cin_pad == 128 && Nn_pad == 8 && x_pitch >= 128) {   // the generator head: phases x padded channels = one 32-row tile
+    const size_t wg_bytes = (size_t)9216 * 16;
+    int ns = (int)(budget / wg_bytes);
+    if (ns > 512) ns = 512;
+    if (ns > ntiles) ns = ntiles;
+    TFC_LAUNCH(tfc_wgrad_head_kernel, dim3(ns), dim3(256), 0, st, (const bf16_t*)x, IH, IW, x_pitch, (const bf16_t*)dy, dy_pitch, N, (float4*)slab, ns);
+    const int nchunk = ns >= 64 ? 8 : 1;
+    TFC_LAUNCH(tfc_wgrad_head_reduce_kernel, dim3(36 * nchunk), dim3(256), 0, st, (const float4*)slab, dwacc, ns, nchunk, Cout, Cin);
+    *err = hipGetLastError();
+    return true;
+  }
   if (up) {
     TFC_LAUNCH(tfc_wgradT_kernel<true>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
                        Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
