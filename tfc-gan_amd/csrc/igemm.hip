@@ -86,7 +86,7 @@ template <> struct TapPat<6> : TapPatRC<3, 3, false> {};   // upsample-conv: eve
 #define TFC_BD2 4          // persistent kernel: weight-ring depth (k-substeps); 3 x 3 tap pattern (18 k-substeps per stage): 2, 3 or 6
 #endif
 #ifndef TFC_BD2_PAT6
-#define TFC_BD2_PAT6 2
+#define TFC_BD2_PAT6 6
 #endif
 template <typename T, int MT, int NT, int WM, int WN, int PAT>
 __global__ void __launch_bounds__(256, TFC_MINW)
