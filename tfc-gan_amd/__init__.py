@@ -7,11 +7,12 @@ Reference surface mirrored here (TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py): U
 Discriminator1 (alias Discriminator), weights_init_normal, make_16_patches, the 16-patch triplet head (ContrastiveLoss),
 FFT_Components / fft_components / calculate_ffts, and the fused TrainStep + data-parallel layer.
 """
-from . import _lib, data, engine, inference, losses, lpips, models, nets, ops, parallel, stn, synthetic  # noqa: F401
+from . import _lib, data, engine, inference, losses, lpips, models, nets, ops, parallel, stn, stn21, synthetic  # noqa: F401
 from ._lib import TfcError, build  # noqa: F401
 from .engine import TrainStep  # noqa: F401
 from .data import DeviceLoader, ImageDataset, TestImageDataset, pair_resize_normalize  # noqa: F401
 from .lpips import LPIPS  # noqa: F401
+from .stn21 import STN21Step  # noqa: F401
 from .stn import Warp, affine_warp, morph_gradient, morph_triplet, triplet_margin_rows  # noqa: F401
 from .synthetic import synthetic_pairs, synthetic_temperatures  # noqa: F401
 from .inference import global_grid, load_clean_state, save_checkpoint, stitch_16_patches  # noqa: F401
@@ -24,4 +25,4 @@ from .models import (BlurPool, Discriminator, Discriminator1, GeneratorUNet, UNe
 __all__ = ["UNetDown", "UNetUp", "GeneratorUNet", "Discriminator1", "Discriminator", "BlurPool", "weights_init_normal",
            "make_16_patches", "ContrastiveLoss", "patch_triplet_loss", "FFT_Components", "fft_components", "calculate_ffts",
            "patch_fft_loss", "global_fft_loss", "mse_spec", "sample_spectra", "vectorize_temps", "temperature_triplet_loss", "color_jitter_thermal",
-           "color_jitter_params", "synthetic_pairs", "synthetic_temperatures", "load_clean_state", "save_checkpoint", "stitch_16_patches", "global_grid", "TrainStep", "LPIPS", "ImageDataset", "TestImageDataset", "DeviceLoader", "pair_resize_normalize", "Warp", "affine_warp", "morph_gradient", "morph_triplet", "triplet_margin_rows", "set_compute_dtype", "get_compute_dtype", "build", "TfcError"]
+           "color_jitter_params", "synthetic_pairs", "synthetic_temperatures", "load_clean_state", "save_checkpoint", "stitch_16_patches", "global_grid", "TrainStep", "STN21Step", "LPIPS", "ImageDataset", "TestImageDataset", "DeviceLoader", "pair_resize_normalize", "Warp", "affine_warp", "morph_gradient", "morph_triplet", "triplet_margin_rows", "set_compute_dtype", "get_compute_dtype", "build", "TfcError"]

@@ -225,9 +225,9 @@ class _GeneratorFn(torch.autograd.Function):
         core = ctx.core
         names = nets.g_param_names()
         grads = {k: torch.empty_like(core.params[k]) for k in names}
-        core.backward(ctx.gctx, g, grads)
+        gx = core.backward(ctx.gctx, g, grads, need_input_grad=ctx.needs_input_grad[1])
         ctx.gctx = None
-        return (None, None, None) + tuple(grads[k] for k in names)
+        return (None, gx, None) + tuple(grads[k] for k in names)
 
 
 class GeneratorUNet(nn.Module):

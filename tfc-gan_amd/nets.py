@@ -160,9 +160,11 @@ class GeneratorCore:
         return fake, ctx
 
     # ---- backward ----
-    def backward(self, ctx, g_fake, grads, hook=None, accumulate=False):
+    def backward(self, ctx, g_fake, grads, hook=None, accumulate=False, need_input_grad=False):
         """g_fake: fp32 NCHW gradient of the loss wrt fake. grads: dict key -> fp32 tensor (torch layout) that receives the
-        parameter gradients (overwritten, or accumulated when `accumulate`). hook(key) fires when a gradient is final."""
+        parameter gradients (overwritten, or accumulated when `accumulate`). hook(key) fires when a gradient is final.
+        need_input_grad: also return d loss / d x as fp32 NCHW (STN21: fake_A2 = generator2(warped_B), STN:629 -- the warp and the localiser
+        train through the generator's input); the PATCH-16 step never asks for it."""
         dt, N = self.dt, ctx.N
         dev = g_fake.device
         ch = self.channels
@@ -231,6 +233,13 @@ class GeneratorCore:
                 tgt = g_skip[i - 1]                               # window of d_{i} gradient already holding the skip-path part
                 ops.conv_dgrad(dt, OP_CONV, d_raw, N, din.H, din.W, cin, cout, self.packed[name]["dgrad"], tgt, accumulate=True)
                 g_cur = tgt
+            elif need_input_grad:
+                w1 = self.params[key]
+                if dt == DT_BF16 and cout == 64 and self.channels <= 4:
+                    return ops.conv_dgrad_image(dt, d_raw, N, din.H, din.W, cin, w1, None, self.channels)   # rows-packed kernel, fp32 NCHW out
+                gx8 = new_act(N, din.H, din.W, din.pitch, dt, dev)
+                ops.conv_dgrad(dt, OP_CONV, d_raw, N, din.H, din.W, cin, cout, ops.pack_weight(dt, OP_CONV, 1, w1.contiguous(), cin, cout), gx8)
+                return ops.unpack_nchw(dt, gx8, self.channels, c0=0)
         return None
 
 
