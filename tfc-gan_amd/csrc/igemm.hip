@@ -1456,6 +1456,19 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
       for (int j = 0; j < 16; ++j) acc[ti][ni][j] = 0.f;
 
   uint4 vdo[NDO], vha[NHA];
+  int hyq[NHA], hxq[NHA], hcq[NHA];
+  bool hok[NHA];
+  {
+    const int nunits = pd.hh * pd.hw * UPN;
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;
+      const int g = idx % UPN, pix = idx / UPN;
+      hyq[i] = pix / pd.hw; hxq[i] = pix - hyq[i] * pd.hw;
+      hcq[i] = cb * 32 + g * UE;
+      hok[i] = idx < nunits && hcq[i] < d.Cin_pad;
+    }
+  }
   auto tile_load = [&](int tl) {
 #ifdef TFC_ABL_WG_SAMETILE
     tl = sp;                                                     // ablation: every load hits the workgroup's first (cache-hot) tile
@@ -1477,19 +1490,14 @@ tfc_wgrad_kernel(const TfcGather d, const T* __restrict__ dO, const T* __restric
         vdo[i] = *reinterpret_cast<const uint4*>(dO + ((size_t)(img * d.OH + oy) * d.OW + ox) * d.out_pitch + n0);
       }
     }
-    const int nunits = pd.hh * pd.hw * UPN;
 #pragma unroll
     for (int i = 0; i < NHA; ++i) {
-      const int idx = tid + i * 256;
       vha[i] = make_uint4(0, 0, 0, 0);
-      if (idx < nunits) {
-        const int g = idx % UPN, pix = idx / UPN;
-        const int hy = pix / pd.hw, hx = pix - hy * pd.hw;
-        const int y = (a0 + pd.dy0 + hy) * d.SS + pd.py;
-        const int x = (b0 + pd.dx0 + hx) * d.SS + pd.px;
-        const int c0 = cb * 32 + g * UE;
-        if (y >= 0 && y < d.IH && x >= 0 && x < d.IW && c0 < d.Cin_pad)
-          vha[i] = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch + c0);
+      if (hok[i]) {                                               // (hy, hx, channel) of a thread's halo units are tile-invariant: computed once per launch
+        const int y = (a0 + pd.dy0 + hyq[i]) * d.SS + pd.py;
+        const int x = (b0 + pd.dx0 + hxq[i]) * d.SS + pd.px;
+        if (y >= 0 && y < d.IH && x >= 0 && x < d.IW)
+          vha[i] = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch + hcq[i]);
       }
     }
   };
