@@ -184,6 +184,16 @@ int tfc_morph_grad_bwd(void* stream, const float* gout, const uint8_t* arg, floa
 int tfc_row_triplet_grad(void* stream, const float* anchor, const float* positive, const float* negative, long long rows, int W, float margin,
                          float gscale, float* loss, float* danchor);
 
+/* ---- first block, backward, fused: UNetDown(channels, 64, normalize=False) (P16:133) and discriminator_block(2 * channels, 64) (P16:183-196) are
+ * conv -> LeakyReLU -> BlurPool(stride 2) with no normalisation. When the gradient of the convolution OUTPUT is needed by nothing but the weight
+ * (and bias) gradient, it is never written: = tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad(TFC_OP_CONV) in one kernel, same bits.
+ * x: NHWC8 input image [N][H][W][8]; y: the stored conv output [N][H-1][W-1] (its sign is all that is read: pre- or post-activation);
+ * dy_pooled: gradient of the pooled output [N][Ho][Wo], Ho = (H-2)/2+1; dw: torch-layout gradient [Cout][Cin][4][4] (=/+=);
+ * bias_sums (nullable): float[N][Cout] += per-image sums of the conv-output gradient; ws: tfc_conv_wgrad_ws_bytes() of scratch (zeroed once). ---- */
+int tfc_first_block_bwd_supported(int dt, int Cin, int Cout);
+int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, int x_pitch, const void* y, int y_pitch, const void* dy_pooled, int dyp_pitch, int N, int H,
+                              int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums);
+
 /* ---- input pipeline: ImageDataset.__getitem__, TFC-GAN-FFT/datasets_temp.py:38-123 --------------------------
  * A decoded file is one RGB uint8 image [H][W][3] with the visible image A in columns [0, xsplit) and the thermal image B in [xsplit, W),
  * xsplit = round-half-even(W / 2) as Image.crop((0, 0, w / 2, h)) does (:54-55). Each half is resized to out x out with PIL's BICUBIC

@@ -214,6 +214,38 @@ def test_first_layer_weights_stationary_kernel(N, H, W, Cin, Cout, with_bias):
     assert (dw.cpu() - 2 * gw).abs().max().item() <= 2 * wtol
 
 
+@pytest.mark.parametrize("N,S,Cin,disc", [(2, 40, 3, False), (1, 70, 6, True), (3, 256, 6, True), (2, 256, 3, False)])
+def test_fused_first_block_backward_equals_unfused_chain(N, S, Cin, disc):
+    """[BlurPool]^T -> LeakyReLU' -> weight / bias gradient of the first block in one kernel (the 266 MB gradient of the conv output is never
+    written) against the chain it replaces, tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad: the same d_raw bits go into the MFMAs, only the
+    split-K summation order differs (fp32 round-off). Reflect aliases on all four borders, partial tiles, with and without accumulate."""
+    dt = DT_BF16
+    assert ops.first_block_bwd_supported(dt, Cin, 64)
+    H = S - 1
+    Po = (H - 1) // 2 + 1
+    xv = to_view(q(rnd((N, Cin, S, S), 5), dt), dt)
+    yv = to_view(q(rnd((N, 64, H, H), 6), dt), dt)                                 # the stored conv output (only its sign matters)
+    gv = to_view(q(rnd((N, 64, Po, Po), 7), dt), dt)
+    d_raw = ops.new_act(N, H, H, 64, dt, DEV, zero=True)
+    r0 = torch.zeros((N, 64), device=DEV)
+    ops.act_bwd(dt, 0, gv, yv, N, H, H, 64, d_raw, stats=None, slope=0.2, pool=2, rstats=r0)
+    dw0 = torch.zeros((64, Cin, 4, 4), device=DEV)
+    ws = ops.conv_wgrad(dt, ops.OP_CONV, xv, d_raw, Cin, 64, dw0)
+    dw1 = torch.full((64, Cin, 4, 4), 5.0, device=DEV)
+    r1 = torch.zeros((N, 64), device=DEV)
+    ws = ops.first_block_bwd_wgrad(dt, xv, yv, gv, Cin, 64, dw1, slope=0.2, ws=ws, bias_sums=r1 if disc else None)
+    scale = dw0.abs().max().item()
+    assert (dw1 - dw0).abs().max().item() <= 2e-5 * scale + 1e-6, (dw1 - dw0).abs().max().item() / scale
+    if disc:
+        assert torch.allclose(r1, r0, rtol=1e-4, atol=1e-3 * r0.abs().max().item())
+    ops.first_block_bwd_wgrad(dt, xv, yv, gv, Cin, 64, dw1, slope=0.2, ws=ws, accumulate=True)
+    assert (dw1 - 2 * dw0).abs().max().item() <= 4e-5 * scale + 1e-6
+    # and the generic path still finds its accumulator zeroed
+    dw2 = torch.zeros_like(dw0)
+    ops.conv_wgrad(dt, ops.OP_CONV, xv, d_raw, Cin, 64, dw2, ws=ws)
+    assert torch.allclose(dw2, dw0, rtol=1e-5, atol=1e-6 * scale)
+
+
 def test_patchgan_head_kernel_matches_padconv():
     for dt in (DT_F32, DT_BF16):
         x = q(rnd((2, 512, 16, 16), 21), dt)

@@ -585,6 +585,38 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
   return 0;
 }
 
+// ---- fused first-block backward --------------------------------------------------------------------------------------------------------
+hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
+                                      void* slab, float* dwacc, float* rstats, float slope, int Nn_real, int Cw_real, hipStream_t st);
+extern "C" int tfc_first_block_bwd_supported(int dt, int Cin, int Cout) { return dt == TFC_DT_BF16 && Cin > 0 && Cin <= 8 && Cout == 64 ? 1 : 0; }
+extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, int x_pitch, const void* y, int y_pitch, const void* dy_pooled, int dyp_pitch,
+                                         int N, int H, int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums) {
+  REQUIRE(tfc_first_block_bwd_supported(dt, Cin, Cout), "fused first-block backward: bf16, Cin <= 8, Cout == 64 (dt=%d Cin=%d Cout=%d)", dt, Cin, Cout);
+  if (int e = check_common(dt, TFC_OP_CONV, N, H, W, Cin, Cout)) return e;
+  REQUIRE(x && y && dy_pooled && ws && dw, "null argument");
+  REQUIRE(x_pitch == 8 && y_pitch >= 64 && y_pitch % 8 == 0 && dyp_pitch >= 64 && dyp_pitch % 8 == 0, "pitches: x %d (must be 8), y %d, dy %d", x_pitch, y_pitch, dyp_pitch);
+  REQUIRE(H >= 4 && W >= 4, "reflect padding of the blur needs a 3 x 3 activation at least");
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(y, "y")) return e;
+  if (int e = check_ptr16(dy_pooled, "dy_pooled")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  TfcGather d;
+  WeightMap wm{};
+  if (int e = build_desc(TFC_OP_CONV, 2, 0, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, &wm)) return e;
+  REQUIRE(d.plane[0].ntaps == 16 && d.plane[0].hh <= TFC_MAX_HH && d.plane[0].hw <= TFC_MAX_HW, "unexpected descriptor");
+  const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;          // pooled size of the (H-1) x (W-1) activation
+  {
+    ProfScope prof(1, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), st, TFC_OP_CONV, 2, N, H, W, Cin, Cout);
+    CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, slope, Cout, Cin, st),
+              "tfc_first_block_bwd_wgrad");
+  }
+  {
+    ProfScope prof(2, 0.0, st, TFC_OP_CONV, 3, N, H, W, Cin, Cout);
+    CHECK_HIP(tfc_launch_wgrad_finish((float*)((char*)ws + kWgradSlabBytes), dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_first_block_bwd_wgrad finish");
+  }
+  return 0;
+}
+
 // ---- fused activation family ------------------------------------------------------------------------------------
 static int fill_act(ActParams& p, int dt, int N, int H, int W, int C, int x_pitch, int o_pitch, int norm, float slope, int pool,
                     float drop_p, uint32_t seed) {

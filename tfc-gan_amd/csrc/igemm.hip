@@ -1768,6 +1768,212 @@ tfc_wgrad_c8_kernel(const TfcGather d, const bf16_t* __restrict__ dO, const bf16
     for (int q4 = 0; q4 < 4; ++q4)
       ps[(ni * 4 + q4) * 64] = make_float4(acc[ni][4 * q4], acc[ni][4 * q4 + 1], acc[ni][4 * q4 + 2], acc[ni][4 * q4 + 3]);
 }
+// ---------------------------------------------------------------------------------------------------
+// First block, backward, fused: [BlurPool(stride 2)]^T -> LeakyReLU' -> weight gradient (+ bias gradient), bf16. The unfused chain
+// (tfc_act_pool2_bwd_kernel, then tfc_wgrad_c8_kernel) is bound by WRITING the 255 x 255 x 64 gradient of the convolution output (266 MB at
+// batch 32; HBM writes run at about half the read rate) and reading it back. When nothing else needs that tensor -- every backward of the first
+// block except the one generator-step pass that continues to the image gradient -- it never has to exist: this kernel is tfc_wgrad_c8_kernel
+// with a PRODUCER in front of its LDS tile. Per 8 x 16 tile of convolution outputs: the 7 x 11 window of the pooled gradient is staged in LDS,
+// every thread turns its four 16-byte units of the stored activation (sign only) into d_raw = (sum of its 2 x 2 -- next to the reflect borders
+// 3 x 3 -- window taps) * (y > 0 ? 1 : slope), rounds to bf16 where the unfused kernel stored it, and writes the dO tile the MFMA loop reads.
+// Reads 266 + 67 + 33 MB, writes 32 KB of slabs per workgroup. Tap weights with the reflect aliases merged are tabulated per tile row / column
+// exactly as in tfc_act_pool2_bwd_kernel, and the arithmetic order is the same, so d_raw -- and with it the weight gradient -- has the same bits.
+// Tiles are dealt out CONTIGUOUSLY (a workgroup stays within one or two images), so the bias-gradient sums leave as 64 atomics per image touched.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fbw(int k) { return (k == 0 || k == 3) ? 0.125f : 0.375f; }
+__global__ void __launch_bounds__(256, 2)
+tfc_wgrad_c8_fused_kernel(const TfcGather d, const bf16_t* __restrict__ yact, int y_pitch, const bf16_t* __restrict__ dyp, int dyp_pitch, int Ho, int Wo,
+                          const bf16_t* __restrict__ in, float4* __restrict__ slab, float* rstats, float slope, int nsplit) {
+  constexpr int ROWB = 64;
+  constexpr int DO_BYTES = 2 * 128 * ROWB;
+  constexpr int HALO_BYTES = (TFC_MAX_HH * TFC_MAX_HW * 16 + 255) & ~255;
+  constexpr int WH = 7, WW = 11, WIN_BYTES = WH * WW * 8 * 16;     // pooled-gradient window: 77 pixels x 64 channels
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DO_BYTES + 2 * HALO_BYTES + WIN_BYTES + 24 * 16 + 2 * 64 * 4];
+  unsigned char* halo0 = smem + DO_BYTES;
+  uint4* win = reinterpret_cast<uint4*>(smem + DO_BYTES + 2 * HALO_BYTES);
+  float4* wrow = reinterpret_cast<float4*>(smem + DO_BYTES + 2 * HALO_BYTES + WIN_BYTES);   // [8] tap weights of pooled rows o0-1, o0, o0+1
+  float4* wcol = wrow + 8;                                                                  // [16]
+  float* sbias = reinterpret_cast<float*>(wcol + 16);                                       // [64] bias-gradient sums of the current image
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TfcPlane& pd = d.plane[0];
+  const int sp = blockIdx.x;
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int t0 = sp * per, t1 = (t0 + per) < ntiles ? (t0 + per) : ntiles;
+  f32x16_t acc[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[ni][j] = 0.f;
+  if (tid < 64) sbias[tid] = 0.f;
+
+  auto decode = [&](int tl, int& img, int& a0, int& b0) {
+    int t = tl;
+    const int txb = t % d.tiles_x; t /= d.tiles_x;
+    const int tyb = t % d.tiles_y;
+    img = t / d.tiles_y;
+    a0 = tyb * TFC_TILE_H; b0 = txb * TFC_TILE_W;
+  };
+  uint4 vy[4], vw[3], vha;
+  auto tile_load = [&](int tl) {
+    int img, a0, b0;
+    decode(tl, img, a0, b0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;                             // (ni * 128 + px) * 4 + g
+      const int g = idx & 3, px = (idx >> 2) & 127, ni = idx >> 9;
+      const int a = a0 + (px >> 4), b = b0 + (px & 15);
+      vy[i] = make_uint4(0, 0, 0, 0);
+      if (a < d.GH && b < d.GW) vy[i] = load_stream16(yact + ((size_t)(img * d.OH + a) * d.OW + b) * y_pitch + ni * 32 + g * 8);
+    }
+    const int oyb = a0 / 2 - 1, oxb = b0 / 2 - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + i * 256;                             // window pixel * 8 + unit
+      const int u = idx & 7, wp = idx >> 3;
+      const int oy = oyb + wp / WW, ox = oxb + wp % WW;
+      vw[i] = make_uint4(0, 0, 0, 0);
+      if (wp < WH * WW && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) vw[i] = *reinterpret_cast<const uint4*>(dyp + ((size_t)(img * Ho + oy) * Wo + ox) * dyp_pitch + u * 8);
+    }
+    vha = make_uint4(0, 0, 0, 0);
+    if (tid < pd.hh * pd.hw) {
+      const int hy = tid / pd.hw, hx = tid - hy * pd.hw;
+      const int y = a0 + pd.dy0 + hy, x = b0 + pd.dx0 + hx;
+      if (y >= 0 && y < d.IH && x >= 0 && x < d.IW) vha = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch);
+    }
+  };
+  // tap weights of one act row / column q of length L (Lo pooled): pooled rows o0-1, o0, o0+1 with o0 = (q+1) >> 1, reflect aliases merged
+  auto taps3 = [&](int q, int L, int Lo) {
+    float w3[3] = {0.f, 0.f, 0.f};
+    if (q < L) {
+      const int o0 = (q + 1) >> 1;
+      for (int a = 0; a < 4; ++a) {
+        if ((a == 1 && q != 1) || (a == 2 && q != L - 2) || (a == 3 && q != L - 3)) continue;
+        const int pq = a == 0 ? q : (a == 1 ? -1 : (a == 2 ? L : L + 1));
+        for (int k = 0; k < 4; ++k) {
+          const int t = pq + 1 - k;
+          if (t < 0 || (t & 1) || (t >> 1) >= Lo) continue;
+          const int dd = (t >> 1) - o0 + 1;
+          if (dd == 0) w3[0] += fbw(k); else if (dd == 1) w3[1] += fbw(k); else if (dd == 2) w3[2] += fbw(k);
+        }
+      }
+    }
+    return make_float4(w3[0], w3[1], w3[2], 0.f);
+  };
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trA = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;
+  const int trB = (8 * hk + q) * 16 + cb16 * 32 + p * 8;
+  auto tr16 = [&](const unsigned char* p0, int rowb4) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + rowb4));
+    uint4 r;
+    r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  };
+  float bsum[2][8];                                              // this thread's channels: ni = 0 / 1, unit g = tid & 3
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[h2][e] = 0.f;
+  int img_cur = -1;
+  auto flush_bias = [&](int img) {                                // all threads; called between barriers
+    if (!rstats || img < 0) return;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { atomicAdd(&sbias[h2 * 32 + (tid & 3) * 8 + e], bsum[h2][e]); bsum[h2][e] = 0.f; }
+    __syncthreads();
+    if (tid < 64) { atomicAdd(&rstats[(size_t)img * 64 + tid], sbias[tid]); sbias[tid] = 0.f; }
+    __syncthreads();
+  };
+
+  if (t0 < t1) tile_load(t0);
+  int cur = 0;
+  for (int tl = t0; tl < t1; ++tl) {
+    int img, a0, b0;
+    decode(tl, img, a0, b0);
+    if (img != img_cur) { flush_bias(img_cur); img_cur = img; }
+    // A. window, halo, tap tables of this tile -> LDS; the activation units stay in registers
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int idx = tid + i * 256; if (idx < WH * WW * 8) win[idx] = vw[i]; }
+    if (tid < TFC_MAX_HH * TFC_MAX_HW) *reinterpret_cast<uint4*>(halo0 + cur * HALO_BYTES + tid * 16) = vha;
+    if (tid < 8) wrow[tid] = taps3(a0 + tid, d.GH, Ho);
+    else if (tid < 24) wcol[tid - 8] = taps3(b0 + tid - 8, d.GW, Wo);
+    uint4 ycur[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ycur[i] = vy[i];
+    __syncthreads();
+    // C. next tile's loads
+    if (tl + 1 < t1) tile_load(tl + 1);
+    // D. d_raw of this tile -> the dO image the MFMA loop reads
+    const int oyb = a0 / 2 - 1, oxb = b0 / 2 - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int g = idx & 3, px = (idx >> 2) & 127, ni = idx >> 9;
+      const int ty = px >> 4, tx = px & 15;
+      const int y = a0 + ty, x = b0 + tx;
+      uint4 res = make_uint4(0, 0, 0, 0);
+      if (y < d.GH && x < d.GW) {
+        float gsum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gsum[e] = 0.f;
+        const float4 wr = wrow[ty], wc = wcol[tx];
+        const int wy = ((y + 1) >> 1) - oyb, wx = ((x + 1) >> 1) - oxb;
+        const int u = ni * 4 + g;
+        auto tap = [&](int dy, int dx, float w) {
+          float v[8];
+          unpack16<bf16_t>(win[((wy + dy) * WW + wx + dx) * 8 + u], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gsum[e] += w * v[e];
+        };
+        tap(-1, -1, wr.x * wc.x); tap(-1, 0, wr.x * wc.y); tap(0, -1, wr.y * wc.x); tap(0, 0, wr.y * wc.y);
+        if (wr.z != 0.f || wc.z != 0.f) {                          // only next to the bottom / right reflect border
+          tap(-1, 1, wr.x * wc.z); tap(0, 1, wr.y * wc.z);
+          tap(1, -1, wr.z * wc.x); tap(1, 0, wr.z * wc.y); tap(1, 1, wr.z * wc.z);
+        }
+        float yv[8];
+        unpack16<bf16_t>(ycur[i], yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gsum[e] = yv[e] > 0.f ? gsum[e] : gsum[e] * slope;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[i >> 1][e] += gsum[e];
+        res = pack16<bf16_t>(gsum);
+      }
+      *reinterpret_cast<uint4*>(smem + idx * 16) = res;
+    }
+    __syncthreads();
+    // F. the weight-gradient MFMAs of tfc_wgrad_c8_kernel
+    {
+      const unsigned char* buf = smem;
+      const unsigned char* hrow = halo0 + cur * HALO_BYTES + wave * pd.hw * 16 + trB;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const uint4 b = tr16(hrow + kt * pd.hw * 16, 4 * 16);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const uint4 a = tr16(buf + ni * 128 * ROWB + kt * 16 * ROWB + trA, 4 * ROWB);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[ni], 0, 0, 0);
+        }
+      }
+    }
+    cur ^= 1;
+  }
+  __syncthreads();
+  flush_bias(img_cur);
+  float4* ps = slab + ((size_t)sp * 4 + wave) * (2 * 4 * 64) + lane;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      ps[(ni * 4 + q4) * 64] = make_float4(acc[ni][4 * q4], acc[ni][4 * q4 + 1], acc[ni][4 * q4 + 2], acc[ni][4 * q4 + 3]);
+}
 // position = ((ky * 2 + ni) * 4 + q4) * 64 + lane of the 2048 float4 of a workgroup slab; block = 256 positions x one of `nchunk` slab ranges
 __global__ void __launch_bounds__(256)
 tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int nchunk, int Nn_real, int Cw_real) {
@@ -2640,6 +2846,17 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
   } else if (slab)
     TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * 4 * (tw * 2) * 4), dim3(256), 0, st, slab, dwacc, d.plane[0], 0, tw * 2, nsplit,
                        nbw * ncb, ncb, Nn_real, Cw_real, -1);
+  return hipGetLastError();
+}
+// fused first-block backward (tfc_wgrad_c8_fused_kernel): d = the TFC_OP_CONV pass-2 descriptor of the layer (8 padded input channels, 64 outputs)
+hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
+                                      void* slab, float* dwacc, float* rstats, float slope, int Nn_real, int Cw_real, hipStream_t st) {
+  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
+  const int ns = ntiles < 512 ? ntiles : 512;
+  TFC_LAUNCH(tfc_wgrad_c8_fused_kernel, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)yact, y_pitch, (const bf16_t*)dyp, dyp_pitch, Ho, Wo,
+             (const bf16_t*)in, (float4*)slab, rstats, slope, ns);
+  const int nchunk = ns >= 16 ? 16 : 1;
+  TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(8 * nchunk), dim3(256), 0, st, (const float4*)slab, dwacc, ns, nchunk, Nn_real, Cw_real);
   return hipGetLastError();
 }
 // transposed convolution / upsample conv, bf16: all four phases in one launch; false = not applicable (caller falls back to per-phase launches)

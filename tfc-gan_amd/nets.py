@@ -215,6 +215,15 @@ class GeneratorCore:
             Hc = raw.H
             dp = drop if ctx.train else 0.0
             sd = ctx.seed * 64 + i
+            key = down_weight_key(name)
+            if (i == 0 and not need_input_grad and not normalize and dp == 0.0 and dbg is None and ops.first_block_bwd_supported(dt, cin, cout)
+                    and pooled(Hc) >= 2):
+                # nothing but this weight gradient needs the 266 MB gradient of the first convolution's output: it is never written (igemm.hip:
+                # tfc_wgrad_c8_fused_kernel = tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad in one kernel, same d_raw bits)
+                self._ws = ops.first_block_bwd_wgrad(dt, din, raw, g_cur, cin, cout, grads[key], slope=0.2, accumulate=accumulate, ws=self._ws)
+                if hook:
+                    hook(key)
+                continue
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             if normalize:
                 rstats = ops.zeros_f32((N, cout, 2), dev)
@@ -340,8 +349,24 @@ class DiscriminatorCore:
             raw, xin = ctx.raw[bi], ctx.ins[bi]
             u, v, sigma2 = ctx.sn[bi]
             Hc = raw.H
-            d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             gb_img = ops.zeros_f32((N, cout), dev) if grads is not None else None
+            fuse = (bi == 0 and grads is not None and not need_input_grad and getattr(self, "debug", None) is None
+                    and ops.first_block_bwd_supported(dt, cin, cout))
+            if fuse:
+                # discriminator step: block 1's conv-output gradient (266 MB) feeds only its weight / bias gradients -> never written
+                W = self.params[f"model.{i}.parametrizations.weight.original"]
+                gsn = torch.empty_like(W)
+                ws = ops.first_block_bwd_wgrad(dt, xin, raw, g_cur, cin, cout, gsn, slope=0.2, ws=ws, bias_sums=gb_img)
+                gbias = grads[f"model.{i}.bias"]
+                if not accumulate:
+                    gbias.zero_()
+                ops.colsum(ops.DT_F32, View(gb_img.view(N, 1, 1, cout), cout), gbias)
+                ops.spectral_norm_bwd(gsn, W, u, v, sigma2, grads[f"model.{i}.parametrizations.weight.original"], accumulate)
+                if hook:
+                    hook(f"model.{i}.parametrizations.weight.original")
+                    hook(f"model.{i}.bias")
+                continue
+            d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
             ddbg = getattr(self, "debug", None)
             if ddbg is not None:

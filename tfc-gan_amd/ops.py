@@ -194,6 +194,25 @@ def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stat
           "tfc_conv_fwd")
 
 
+def first_block_bwd_supported(dt, Cin, Cout):
+    import os
+    if os.environ.get("TFC_NO_FUSED_FIRST_BWD"):                  # A/B knob for profiling
+        return False
+    return bool(lib().tfc_first_block_bwd_supported(dt, Cin, Cout))
+
+
+def first_block_bwd_wgrad(dt, x: View, y: View, dy_pooled: View, Cin, Cout, dw, slope=0.2, accumulate=False, ws=None, bias_sums=None):
+    """[BlurPool]^T -> LeakyReLU' -> weight (+ bias) gradient of the first block in one kernel: the gradient of the conv output is never written"""
+    nbytes = lib().tfc_conv_wgrad_ws_bytes(OP_CONV, Cin, Cout)
+    if ws is None or ws.numel() * ws.element_size() < nbytes:
+        nbig = lib().tfc_conv_wgrad_ws_bytes(OP_CONV, 1024, 512)
+        ws = torch.zeros(max(nbytes, nbig), dtype=torch.uint8, device=x.t.device)
+    assert dw.dtype == torch.float32 and dw.is_contiguous()
+    check(lib().tfc_first_block_bwd_wgrad(stream_ptr(), dt, x.ptr, x.pitch, y.ptr, y.pitch, dy_pooled.ptr, dy_pooled.pitch, x.N, x.H, x.W, Cin, Cout, slope,
+                                          _p(ws), _p(dw), 1 if accumulate else 0, _p(bias_sums)), "tfc_first_block_bwd_wgrad")
+    return ws
+
+
 def conv_dgrad_image(dt, dy: View, N, H, W, Cin, w, oscale, nch):
     """first discriminator conv, gradient w.r.t. its first `nch` input channels as fp32 NCHW [N,nch,H,W] (bf16 path)"""
     out = torch.empty((N, nch, H, W), dtype=torch.float32, device=dy.t.device)
