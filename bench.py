@@ -190,6 +190,8 @@ def main():
     recs = T.ops.prof_records(16384)
     ig_ms, ig_flop, ig_n = T.ops.prof_collect(0)
     wg_ms, wg_flop, wg_n = T.ops.prof_collect(1)
+    T.ops.prof_collect(2)                                 # wgrad finish passes (no algorithmic FLOP of their own)
+    fb_ms, fb_flop, fb_n = T.ops.prof_collect(3)          # fused first-block backward ([BlurPool]^T + LeakyReLU' + weight gradient in one launch)
     # the dominant kernel proper: class-0 calls that dispatch tfc_igemm2_kernel (bf16, whole 64-byte channel chunks, NHWC output); the rest of
     # class 0 (first-layer tfc_conv_c8_kernel, the two 3-channel heads) is reported beside it
     p8 = lambda c: (c + 7) // 8 * 8  # noqa: E731
@@ -232,8 +234,10 @@ def main():
                          "instrumented_steps": nprof, "share_of_step_time": (dom_ms / 1e3 / nprof) / step_s,
                          "whole_conv_class": {"kernels": "tfc_igemm2_kernel + tfc_conv_c8_kernel + 3-channel head kernels", "achieved": (ig_flop / 1e12) / (ig_ms / 1e3) if ig_ms > 0 else 0.0,
                                               "unit": "TFLOP/s", "calls": ig_n, "share_of_step_time": (ig_ms / 1e3 / nprof) / step_s},
-                         "second_kernel": {"kernel": "tfc_wgrad_kernel", "achieved": (wg_flop / 1e12) / (wg_ms / 1e3) if wg_ms > 0 else 0.0,
-                                           "unit": "TFLOP/s", "launches": wg_n, "share_of_step_time": (wg_ms / 1e3 / nprof) / step_s}},
+                         "second_kernel": {"kernel": "tfc_wgrad_kernel family (incl. slab reduction)", "achieved": (wg_flop / 1e12) / (wg_ms / 1e3) if wg_ms > 0 else 0.0,
+                                           "unit": "TFLOP/s", "launches": wg_n, "share_of_step_time": (wg_ms / 1e3 / nprof) / step_s},
+                         "fused_first_block_backward": {"kernel": "tfc_wgrad_c8_fused_kernel (VALU-bound transposed blur + first-layer weight gradient)",
+                                                        "calls": fb_n, "avg_call_ms": fb_ms / max(fb_n, 1), "share_of_step_time": (fb_ms / 1e3 / nprof) / step_s}},
             "whole_step_tflops": T.TrainStep.STEP_GFLOP * value / 1e3,
             "final_losses": {"loss_G": loss_g, "loss_D": loss_d},
         }

@@ -230,7 +230,8 @@ int tfc_lpips_head(void* stream, int dt, const void* fx, const void* fy, const f
 
 /* ---- measurement -------------------------------------------------------------------------------------------------- */
 /* When enabled every gather-GEMM / wgrad launch is bracketed by hipEvents on its own stream; tfc_prof_collect()
- * (call after synchronising) sums them per kernel class: 0 = tfc_igemm_kernel family, 1 = tfc_wgrad family (+ slab reduce). */
+ * (call after synchronising) sums them per kernel class: 0 = tfc_igemm_kernel family, 1 = tfc_wgrad family (+ slab reduce),
+ * 2 = the wgrad finish pass, 3 = the fused first-block backward (transposed blur + weight gradient in one launch). */
 int tfc_prof_enable(int on);
 int tfc_prof_collect(int kclass, double* total_ms, double* algorithmic_flop, long long* launches);
 /* per-call detail of the records gathered on this thread since the last collect (kclass 2 = the wgrad finish pass): arrays of max_records entries,

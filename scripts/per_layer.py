@@ -20,6 +20,7 @@ CONV_KERNELS = ("tfc_igemm_kernel", "tfc_conv_c8_kernel", "tfc_upconv_head_kerne
                 "tfc_wgradT_kernel", "tfc_wgrad_reduce_kernel", "tfc_wgrad_finish_kernel", "tfc_igemm2_kernel", "tfc_wgrad_fin_kernel", "tfc_wgrad_reduce_fin_kernel", "tfc_wgrad_c8_kernel", "tfc_wgrad_c8_reduce_kernel", "tfc_wgrad_head_kernel", "tfc_wgrad_head_reduce_kernel", "tfc_wgrad_c8_fused_kernel")
 OPN = {0: "conv", 1: "padconv", 2: "convT", 3: "upconv"}
 PASSN = {0: "fwd", 1: "dgrad", 2: "wgrad", 3: "wgrad-finish"}
+CLASSN = {0: "gather GEMM", 1: "weight gradient (+ slab reduce)", 2: "wgrad finish", 3: "fused first-block backward ([BlurPool]^T + LeakyReLU' + wgrad)"}
 
 
 def short(name):
@@ -74,7 +75,7 @@ def main():
     out.append("")
     for kclass, (us, fl) in sorted(tot.items()):
         if us > 0:
-            out.append(f"class {kclass}: {us / 1e3:.2f} ms total, {fl / us / 1e6:.0f} TFLOP/s = {fl / us / 1e6 / PEAK:.3f} of peak")
+            out.append(f"class {kclass} ({CLASSN.get(kclass, '?')}): {us / 1e3:.2f} ms total, {fl / us / 1e6:.0f} TFLOP/s = {fl / us / 1e6 / PEAK:.3f} of peak")
     # wgrad family including its finish pass
     us_w = tot[1][0] + tot[2][0]
     if us_w > 0:

@@ -606,7 +606,9 @@ extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, in
   REQUIRE(d.plane[0].ntaps == 16 && d.plane[0].hh <= TFC_MAX_HH && d.plane[0].hw <= TFC_MAX_HW, "unexpected descriptor");
   const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;          // pooled size of the (H-1) x (W-1) activation
   {
-    ProfScope prof(1, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), st, TFC_OP_CONV, 2, N, H, W, Cin, Cout);
+    // class 3, not 1: this launch also carries the (VALU-bound) transposed blur that used to be an elementwise pass of its own -- keeping it out of
+    // the weight-gradient class keeps that class comparable across rounds
+    ProfScope prof(3, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), st, TFC_OP_CONV, 2, N, H, W, Cin, Cout);
     CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, slope, Cout, Cin, st),
               "tfc_first_block_bwd_wgrad");
   }
