@@ -137,6 +137,16 @@ class DeviceLoader:
         n = len(self.ds)
         return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
 
+    def close(self):
+        """stop the decode threads (also runs when the loader is garbage-collected)"""
+        self.pool.shutdown(wait=False, cancel_futures=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _assemble(self, arrays):
         groups = {}
         for i, a in enumerate(arrays):

@@ -4,6 +4,7 @@ Activations are torch tensors of physical shape [N, H, W, pitch] (NHWC); a `View
 [coff, coff + C) of such a buffer, which is how skip connections share one concat buffer without copies.
 """
 import ctypes
+import os
 from dataclasses import dataclass
 
 import torch
@@ -195,7 +196,6 @@ def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stat
 
 
 def first_block_bwd_supported(dt, Cin, Cout):
-    import os
     if os.environ.get("TFC_NO_FUSED_FIRST_BWD"):                  # A/B knob for profiling
         return False
     return bool(lib().tfc_first_block_bwd_supported(dt, Cin, Cout))
