@@ -74,6 +74,9 @@ int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int 
  * Same result as tfc_conv_fwd(TFC_OP_UPCONV, TFC_EP_BIAS | TFC_EP_TANH_NCHW); the four sub-pixel phases share one 16-wide MFMA tile. */
 int tfc_upconv_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const float* w,
                         const float* bias, float* out_nchw);
+/* its input gradient: dy NHWC8 [N][2H][2W][8] (Cout <= 8 real channels) -> dx NHWC [N][H][W] channels [0,128) at dx_pitch, overwritten.
+ * w: the fp32 torch-layout filter [Cout][128][4][4] (the collapsed taps are summed in fp32 and rounded to bf16 once, as in the forward). */
+int tfc_upconv_head_dgrad(void* stream, int dt, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout, const float* w, void* dx, int dx_pitch);
 
 /* input gradient of the FIRST discriminator convolution (nn.Conv2d(Cin, 64, 4, stride 1, padding 1), P16:188) w.r.t. its first `nch`
  * (<= 4) input channels -- the generated image inside cat(img_A, img_B), P16:205 -- written as fp32 NCHW [N][nch][H][W]; bf16 only.

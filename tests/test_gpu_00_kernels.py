@@ -291,6 +291,27 @@ def test_generator_head_kernel(N, H, W, Cout, with_bias):
     assert (out - old).abs().max().item() <= 2e-5                    # same bf16 operands, fp32 accumulation in a different order
 
 
+@pytest.mark.parametrize("N,H,W,Cout", [(2, 16, 16, 3), (1, 9, 10, 3), (3, 21, 40, 1), (4, 128, 128, 3)])
+def test_generator_head_dgrad_kernel(N, H, W, Cout):
+    """tfc_upconv_head_dgrad (collapsed 5 x 5 stride-2 window of dy, weights-stationary) against torch autograd on bf16-rounded operands and
+    against the gather-GEMM path it replaces; ragged tiles, several tiles per workgroup, a destination window of a wider buffer"""
+    dt = DT_BF16
+    x = q(rnd((N, 128, H, W), 5), dt).requires_grad_(True)
+    w = rnd((Cout, 128, 4, 4), 6, 0.05)
+    y = ref_conv(ops.OP_UPCONV, x, w)
+    go = q(rnd(tuple(y.shape), 7), dt)
+    (gx,) = torch.autograd.grad(y, x, go)
+    gov = to_view(go, dt)
+    buf = torch.full((N, H, W, 160), 3.0, dtype=torch.bfloat16, device=DEV)
+    ops.upconv_head_dgrad(dt, gov, N, H, W, w.to(DEV), View(buf, 128, 0))
+    got = buf[..., :128].float().cpu().permute(0, 3, 1, 2)
+    assert (buf[..., 128:] == 3.0).all()
+    assert (got - gx).abs().max().item() <= tol(dt, gx.abs().max().item())
+    old = ops.new_act(N, H, W, 128, dt, DEV, zero=True)
+    ops.conv_dgrad(dt, ops.OP_UPCONV, gov, N, H, W, 128, Cout, ops.pack_weight(dt, ops.OP_UPCONV, 1, w.to(DEV), 128, Cout), old)
+    assert (got - from_view(old)).abs().max().item() <= 2e-2 * gx.abs().max().item()     # both round the collapsed taps once, sums in different order
+
+
 @pytest.mark.parametrize("N,H,W", [(2, 16, 16), (1, 37, 50), (5, 96, 64)])
 def test_first_conv_dgrad_image(N, H, W):
     """tfc_conv_dgrad_image (four output rows packed into the columns of a 16-wide MFMA tile) against autograd on bf16-rounded operands"""

@@ -458,6 +458,20 @@ extern "C" int tfc_conv_dgrad_image(void* stream, int dt, const void* dy, int dy
   return 0;
 }
 
+hipError_t tfc_launch_dgrad_head(const void* dy, int dy_pitch, int N, int H, int W, const float* w, int Cout, void* dx, int dx_pitch, hipStream_t st);
+extern "C" int tfc_upconv_head_dgrad(void* stream, int dt, const void* dy, int dy_pitch, int N, int H, int W, int Cin, int Cout, const float* w, void* dx,
+                                     int dx_pitch) {
+  REQUIRE(dt == TFC_DT_BF16 && Cin == 128 && Cout >= 1 && Cout <= 8, "tfc_upconv_head_dgrad: bf16, Cin == 128, Cout <= 8 only (use tfc_conv_dgrad(TFC_OP_UPCONV) otherwise)");
+  REQUIRE(dy && w && dx && N > 0 && H > 1 && W > 1 && dy_pitch >= 8 && dy_pitch % 8 == 0 && dx_pitch >= 128 && dx_pitch % 8 == 0, "bad args");
+  REQUIRE((long long)N * H * W * dx_pitch < 2147483647LL, "tensor exceeds 2^31 elements");
+  if (int e = check_ptr16(dy, "dy")) return e;
+  if (int e = check_ptr16(dx, "dx")) return e;
+  if (int e = check_ptr16(w, "w")) return e;
+  ProfScope prof(0, conv_flop(TFC_OP_UPCONV, N, H, W, Cin, Cout), (hipStream_t)stream, TFC_OP_UPCONV, 1, N, H, W, Cin, Cout);
+  CHECK_HIP(tfc_launch_dgrad_head(dy, dy_pitch, N, H, W, w, Cout, dx, dx_pitch, (hipStream_t)stream), "tfc_upconv_head_dgrad");
+  return 0;
+}
+
 extern "C" int tfc_upconv_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const float* w,
                                   const float* bias, float* out_nchw) {
   REQUIRE(dt == TFC_DT_BF16 && Cin == 128 && Cout >= 1 && Cout <= 4, "tfc_upconv_head_fwd: bf16, Cin == 128, Cout <= 4 only (use tfc_conv_fwd(TFC_OP_UPCONV) otherwise)");

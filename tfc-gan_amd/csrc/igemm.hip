@@ -1248,6 +1248,161 @@ hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Input gradient of the generator head (Upsample x2 -> ZeroPad(1,0,1,0) -> Conv2d(128, C <= 8, 4, padding=1); P16:150-157), bf16:
+//   dx[a][b][ci] = sum_{m,n = 0..4} sum_oc dy[2a-1+m][2b-1+n][oc] * Wd[m][n][oc][ci],   Wd[m][n] = sum_{ky in S(m), kx in S(n)} w[oc][ci][ky][kx],
+//   S = {3}, {2,3}, {1,2}, {0,1}, {0}   (the filter taps whose up-sampled source row is a, seen from dy row 2a-1+m).
+// The generic kernel ran this on 16-byte channel chunks without a compile-time tap pattern (114 us); its bound is the 134 MB dx stream (~40 us).
+// Here: K = 25 positions x 8 padded channels = 13 k-substeps of two positions; the collapsed filter is built ONCE per wave from the fp32
+// weights as register-resident B fragments (weights-stationary, persistent workgroups, like tfc_conv_c8_kernel); the (2*8+3) x (2*16+3) halo
+// of dy is staged in LDS (16 B per pixel) and read at stride-2 pixel addresses; 128 pixels x 128 channels per workgroup, wave = 128 pixels x 32 channels.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tfc_dgrad_head_kernel(const bf16_t* __restrict__ dy, int dy_pitch, const float* __restrict__ w, int Cout, bf16_t* __restrict__ dx, int dx_pitch,
+                      int IH, int IW, int nimg, int nwork) {
+  constexpr int HR = 2 * TFC_TILE_H + 3, HC = 2 * TFC_TILE_W + 3, P = 36;   // 19 x 35 halo of dy, LDS pitch 36 pixels
+  constexpr int HB = HR * P * 16;
+  constexpr int ROWP = 128 * 2 + 16;                             // staged output tile: 128 channels per pixel row + pad
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HB + 128 * ROWP];
+  unsigned char* stage = smem + 2 * HB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave;                                           // this wave: input channels 32 wn .. 32 wn + 31, all 128 pixels (4 m-tiles)
+  const int h = lane >> 5, r = lane & 31;
+  const int G = gridDim.x;
+  const int OH = 2 * IH, OW = 2 * IW;
+  const int tiles_y = (IH + TFC_TILE_H - 1) / TFC_TILE_H, tiles_x = (IW + TFC_TILE_W - 1) / TFC_TILE_W;
+
+  // ---- B fragments: bw[s][nt], element e = oc of position t = 2s + h, column ci = (wn * 2 + nt) * 32 + r ----
+  uint4 bw[13];
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    const int t = 2 * s + h, m = t / 5, n = t - 5 * m;
+    // S(m): filter rows ky in [ylo, yhi]
+    const int ylo = m == 0 ? 3 : (m == 4 ? 0 : 3 - m), yhi = m == 0 ? 3 : (m == 4 ? 0 : 4 - m);
+    const int xlo = n == 0 ? 3 : (n == 4 ? 0 : 3 - n), xhi = n == 0 ? 3 : (n == 4 ? 0 : 4 - n);
+    {
+      const int ci = wn * 32 + r;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float acc = 0.f;
+        if (e < Cout && t < 25)
+          for (int ky = ylo; ky <= yhi; ++ky)
+            for (int kx = xlo; kx <= xhi; ++kx) acc += w[((size_t)e * 128 + ci) * 16 + ky * 4 + kx];
+        f[e] = acc;
+      }
+      bw[s] = pack16<bf16_t>(f);
+    }
+  }
+  // per-lane LDS offset of position t = 2s + h relative to the lane's pixel (compile-time per (s, h); selected once)
+  int offs[13];
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    const int t0 = 2 * s, t1 = 2 * s + 1 < 25 ? 2 * s + 1 : 24;  // slot 25 carries zero weights: any valid address
+    const int o0 = ((t0 / 5) * P + t0 % 5) * 16, o1 = ((t1 / 5) * P + t1 % 5) * 16;
+    offs[s] = h ? o1 : o0;
+  }
+  auto decode = [&](int wk, int& img, int& a0, int& b0) {
+    int tile = tfc_xcd_remap(wk, nwork);
+    const int txb = tile % tiles_x; tile /= tiles_x;
+    const int tyb = tile % tiles_y;
+    img = tile / tiles_y;
+    a0 = tyb * TFC_TILE_H; b0 = txb * TFC_TILE_W;
+  };
+  constexpr int NHV = (HR * HC + 255) / 256;                     // halo pixels per thread (3)
+  int hoff[NHV], hy[NHV], hx[NHV];
+#pragma unroll
+  for (int i = 0; i < NHV; ++i) {
+    const int hp = tid + i * 256;
+    hy[i] = hp / HC; hx[i] = hp - hy[i] * HC;
+    hoff[i] = hp < HR * HC ? (hy[i] * P + hx[i]) * 16 : -1;
+  }
+  uint4 hv[NHV];
+  auto halo_load = [&](int img, int a0, int b0) {
+#pragma unroll
+    for (int i = 0; i < NHV; ++i) {
+      const int y = 2 * a0 - 1 + hy[i], x = 2 * b0 - 1 + hx[i];
+      hv[i] = make_uint4(0, 0, 0, 0);
+      if (hoff[i] >= 0 && y >= 0 && y < OH && x >= 0 && x < OW) hv[i] = *reinterpret_cast<const uint4*>(dy + ((size_t)(img * OH + y) * OW + x) * dy_pitch);
+    }
+  };
+  auto halo_store = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NHV; ++i)
+      if (hoff[i] >= 0) *reinterpret_cast<uint4*>(buf + hoff[i]) = hv[i];
+  };
+  // lane pixel of m-tile ms: ty = 2 * ms + (r & 1), tx = r >> 1 -> halo pixel (2 ty, 2 tx)
+  const int laneBase = ((2 * (r & 1)) * P + 2 * (r >> 1)) * 16;
+  constexpr int MSTRIDE = 4 * P * 16;                            // next m-tile: ty + 2 -> 4 halo rows
+
+  int wk = blockIdx.x;
+  if (wk >= nwork) return;
+  int img, a0, b0;
+  decode(wk, img, a0, b0);
+  halo_load(img, a0, b0);
+  halo_store(smem);
+  __syncthreads();
+  for (int k = 0;; ++k) {
+    const bool more = wk + G < nwork;
+    int n_img = 0, n_a0 = 0, n_b0 = 0;
+    if (more) { decode(wk + G, n_img, n_a0, n_b0); halo_load(n_img, n_a0, n_b0); }
+    const unsigned char* buf = smem + (k & 1) * HB + laneBase;
+    f32x16_t acc[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 13; ++s) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const uint4 a = *reinterpret_cast<const uint4*>(buf + offs[s] + mi * MSTRIDE);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[s]), acc[mi], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+        const int ty = 2 * mi + (row & 1), tx = row >> 1;
+        *reinterpret_cast<bf16_t*>(stage + (ty * TFC_TILE_W + tx) * ROWP + (wn * 32 + r) * 2) = f32_to_bf16(acc[mi][j]);
+      }
+    if (more) halo_store(smem + ((k + 1) & 1) * HB);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      const int pix = idx >> 4, u = idx & 15;
+      const int a = a0 + (pix >> 4), b = b0 + (pix & 15);
+      if (a < IH && b < IW) {
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * ROWP + u * 16);
+        store_stream16(dx + ((size_t)(img * IH + a) * IW + b) * dx_pitch + u * 8, v);
+      }
+    }
+    if (!more) break;
+    __syncthreads();
+    wk += G; img = n_img; a0 = n_a0; b0 = n_b0;
+  }
+}
+hipError_t tfc_launch_dgrad_head(const void* dy, int dy_pitch, int N, int H, int W, const float* w, int Cout, void* dx, int dx_pitch, hipStream_t st) {
+  static int grid_cap = 0;
+  if (!grid_cap) {
+    int occ = 0, dev = 0, ncu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_dgrad_head_kernel, 256, 0);
+    if (e != hipSuccess) return e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    grid_cap = (occ < 1 ? 1 : occ) * ncu;
+  }
+  const int nwork = N * ((H + TFC_TILE_H - 1) / TFC_TILE_H) * ((W + TFC_TILE_W - 1) / TFC_TILE_W);
+  TFC_LAUNCH(tfc_dgrad_head_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, (const bf16_t*)dy, dy_pitch, w, Cout, (bf16_t*)dx, dx_pitch, H, W, N,
+             nwork);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight-gradient GEMM for 2 x 2-tap planes (bf16): the sub-pixel phases of the transposed convolution and phase (0,0) of the
 // upsample-conv. With only four taps the generic kernel gives each wave ONE tap (3 transposing LDS reads per MFMA); here a
 // workgroup owns 64 n x 64 c and wave (nh, ch) owns the 32 n x 32 c quadrant for ALL four taps: the B fragments of halo rows

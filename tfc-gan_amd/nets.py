@@ -177,7 +177,10 @@ class GeneratorCore:
             hook("final.2.weight")
             hook("final.2.bias")
         g_cat = new_act(N, ctx.u5.H, ctx.u5.W, ctx.u5.pitch, dt, dev)
-        ops.conv_dgrad(dt, OP_UPCONV, dyf, N, ctx.u5.H, ctx.u5.W, 128, ch, self.packed["final"]["dgrad"], g_cat)
+        if dt == DT_BF16 and ch <= 8 and ctx.u5.pitch == 128:
+            ops.upconv_head_dgrad(dt, dyf, N, ctx.u5.H, ctx.u5.W, self.params["final.2.weight"], g_cat)    # weights-stationary head kernel
+        else:
+            ops.conv_dgrad(dt, OP_UPCONV, dyf, N, ctx.u5.H, ctx.u5.W, 128, ch, self.packed["final"]["dgrad"], g_cat)
         dbg = getattr(self, "debug", None)
         if dbg is not None:
             dbg["dyf"], dbg["g_u5"] = dyf, ops.View(g_cat.t.clone(), g_cat.C)   # clone: the skip window is accumulated into later

@@ -228,6 +228,11 @@ def upconv_head_fwd(dt, x: View, w, bias, out_nchw):
           "tfc_upconv_head_fwd")
 
 
+def upconv_head_dgrad(dt, dy: View, N, H, W, w, dx: View):
+    """input gradient of the generator head (bf16, 128 input channels, <= 8 output channels): dy NHWC8 at 2H x 2W -> dx [N,H,W,128]"""
+    check(lib().tfc_upconv_head_dgrad(stream_ptr(), dt, dy.ptr, dy.pitch, N, H, W, 128, w.shape[0], _p(w), dx.ptr, dx.pitch), "tfc_upconv_head_dgrad")
+
+
 def patchgan_head_fwd(dt, x: View, w, y: View):
     check(lib().tfc_patchgan_head_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, x.C, _p(w), y.ptr, y.pitch), "tfc_patchgan_head_fwd")
 
