@@ -2911,7 +2911,7 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
     // the CUs idle: 50 -> 57 us, excluded; the four sub-pixel phases of a transposed convolution count as tiles).
     static const bool old_rule = [] { const char* e = getenv("TFC_TILE_RULE_OLD"); return e && atoi(e) != 0; }();   // A/B knob for profiling
     const int w128 = ntiles * (d.ph_n > 1 ? d.ph_n : 1) * ((nb + 3) / 4);
-    if (!old_rule && nb >= 4 && d.Cin_pad >= 64 && w128 >= tfc_num_cus() && w128 < 2048)   // (also 1-3 % ahead of <2,2,2,2> at 32 x 32 256->512; the two are equal beyond)
+    if (!old_rule && nb >= 4 && d.Cin_pad >= 64 && w128 >= tfc_num_cus() && (w128 < 2048 || d.Cin_pad >= 128))   // (128 -> 256 at 64 x 64: 130 -> 124 us; 64 -> 128 at 128 x 128 stays on <2,2,2,2>: 132 vs 157)   // (also 1-3 % ahead of <2,2,2,2> at 32 x 32 256->512; the two are equal beyond)
       return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   }
   if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
