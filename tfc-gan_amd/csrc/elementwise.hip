@@ -1310,10 +1310,13 @@ hipError_t tfc_launch_cast(int dt, int to_f32, const void* x, void* y, long long
   return hipGetLastError();
 }
 
+#ifndef TFC_HEAD_NB
+#define TFC_HEAD_NB 512
+#endif
 hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st) {
   const int npix = N * H * W;
   int nb = (npix + 3) / 4;
-  if (nb > 512) nb = 512;                                        // the filter is loaded once per wave: few, long-lived workgroups
+  if (nb > TFC_HEAD_NB) nb = TFC_HEAD_NB;                        // the filter is loaded once per wave: few, long-lived workgroups
   const int ue = dt == TFC_DT_BF16 ? 8 : 4;
   const size_t lds = (C / ue <= 64) ? 0 : (size_t)16 * C * sizeof(float);
   if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_head_fwd_kernel<bf16_t>), dim3(nb), dim3(256), lds, st, (const bf16_t*)x, x_pitch, w, (bf16_t*)y, y_pitch, N, H, W, C);
