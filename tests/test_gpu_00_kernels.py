@@ -246,6 +246,30 @@ def test_fused_first_block_backward_equals_unfused_chain(N, S, Cin, disc):
     assert torch.allclose(dw2, dw0, rtol=1e-5, atol=1e-6 * scale)
 
 
+def test_planned_pack_equals_single_pack():
+    """tfc_conv_pack_planned (one launch for every operand stream of a network; single-slot taps take a scan-free path) writes the same bytes
+    as tfc_conv_pack, for every op and pass of the path -- plain, flipped (dgrad), phase-split (transposed conv), collapsed (upsample head), 3x3"""
+    for dt in (DT_BF16, DT_F32):
+        jobs, refs = [], []
+        cases = [(ops.OP_CONV, 64, 128), (ops.OP_CONV, 3, 64), (ops.OP_CONV, 512, 512), (ops.OP_PADCONV, 512, 1), (ops.OP_CONVT, 256, 64),
+                 (ops.OP_CONVT, 1024, 512), (ops.OP_UPCONV, 128, 3)] + ([(ops.OP_CONV3, 64, 128)] if dt == DT_BF16 else [(ops.OP_CONV3, 32, 64)])
+        for k, (op, cin, cout) in enumerate(cases):
+            shape = (cin, cout, 4, 4) if op == ops.OP_CONVT else (cout, cin, 4, 4)
+            w = rnd(shape, 100 + k, 0.1).to(DEV)
+            for pas in (0, 1):
+                jobs.append((op, pas, w, cin, cout))
+                pre = torch.full((ops.packed_bytes(dt, op, pas, cin, cout),), 0x5A, dtype=torch.uint8, device=DEV)   # slack k-substeps stay untouched
+                refs.append(ops.pack_weight(dt, op, pas, w, cin, cout, out=pre))
+        plan = ops.PackPlan(dt, jobs)
+        for st in plan.streams:
+            st.fill_(0x5A)
+        plan.run()
+        torch.cuda.synchronize()
+        for (op, pas, _, cin, cout), got, want in zip(jobs, plan.streams, refs):
+            assert torch.equal(got, want), (dt, op, pas, cin, cout, int((got != want).sum()))
+            assert (got != 0x5A).any()
+
+
 def test_patchgan_head_kernel_matches_padconv():
     for dt in (DT_F32, DT_BF16):
         x = q(rnd((2, 512, 16, 16), 21), dt)
