@@ -164,7 +164,8 @@ int tfc_row_triplet(void* stream, const float* anchor, const float* positive, co
 /* out[0] (=/+=) scale * sum |a-b| : nn.L1Loss pieces of calculate_ffts, P16:323-375 */
 int tfc_l1_sum(void* stream, const float* a, const float* b, long long n, float scale, float* out, int zero_first);
 /* relativistic BCEWithLogits, P16:554 (mode 0) and P16:628-630 (mode 1); a,b: n logits in dt, `stride` elements apart
- * (the PatchGAN head stores its single channel at pixel pitch 8); loss fp32 scalar; da/db (nullable) = gscale * dloss */
+ * (the PatchGAN head stores its single channel at pixel pitch 8); loss fp32 scalar; da/db (nullable) = gscale * dloss. With stride == 8 the
+ * WHOLE 8-channel pixel of da / db is written (gradient, seven zeros): the head's input-gradient pass reads all eight, no pre-zeroing needed */
 int tfc_bce_relativistic(void* stream, int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode,
                          float* loss, void* da, void* db, float gscale);
 /* torch.optim.Adam step (P16:461-462) on flat fp32 buffers; step >= 1; gscale multiplies the gradient (1/world size) */

@@ -608,6 +608,20 @@ def test_bce_relativistic_golden(golden):
         assert torch.allclose(from_view(View(da.t, 1)), ar.grad, atol=1e-8) and torch.allclose(from_view(View(db.t, 1)), br.grad, atol=1e-8)
 
 
+@pytest.mark.parametrize("dt", [DT_BF16, DT_F32])
+def test_bce_gradient_writes_whole_pixels(dt):
+    """the logit gradient lives in channel 0 of an 8-channel pixel whose other channels the head's input-gradient GEMM reads as zeros: the kernel
+    must write all eight (the engine hands it UNINITIALISED buffers)"""
+    N, H = 3, 16
+    a = ops.View(torch.randn((N, H, H, 8), device=DEV).to(ops.torch_dtype(dt)), 1)
+    b = ops.View(torch.randn((N, H, H, 8), device=DEV).to(ops.torch_dtype(dt)), 1)
+    da = torch.full((N, H, H, 8), 7.0, dtype=ops.torch_dtype(dt), device=DEV)
+    db = torch.full((N, H, H, 8), -7.0, dtype=ops.torch_dtype(dt), device=DEV)
+    ops.bce_relativistic(dt, a, b, 1, 0.9, 0.0, da=View(da, 1, 0), db=View(db, 1, 0))
+    assert (da[..., 1:] == 0).all() and (db[..., 1:] == 0).all()
+    assert (da[..., 0].float().abs() > 0).any() and torch.equal(da[..., 0].float(), -db[..., 0].float())
+
+
 def test_adam_vs_oracle():
     p, m, v = rnd((1000,), 1), torch.zeros(1000), torch.zeros(1000)
     pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)

@@ -1007,8 +1007,20 @@ tfc_bce_rel_kernel(const T* __restrict__ a, const T* __restrict__ b, int n, int 
       l += 0.5f * (bce_logits(x, t1) + bce_logits(-x, t2));
       gx = 0.5f * ((sigmoidf_(x) - t1) - (sigmoidf_(-x) - t2)) * invn;
     }
-    if (da) ElemTraits<T>::st(da + (size_t)i * stride, gx * gscale);
-    if (db) ElemTraits<T>::st(db + (size_t)i * stride, -gx * gscale);
+    // the logit lives in channel 0 of an 8-channel pixel (pitch `stride`) whose other channels the consumer (the head's input-gradient GEMM)
+    // reads as zeros: write the whole pixel, so the caller need not zero the buffer first (three fill launches per step)
+    auto put = [&](T* dst, float v) {
+      constexpr int UE = ElemTraits<T>::UE;
+      if (stride == 8 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        float z[8] = {v, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<uint4*>(dst) = pack16<T>(z);
+        if (UE == 4) *reinterpret_cast<uint4*>(dst + 4) = pack16<T>(z + 4);
+      } else {
+        ElemTraits<T>::st(dst, v);
+      }
+    };
+    if (da) put(da + (size_t)i * stride, gx * gscale);
+    if (db) put(db + (size_t)i * stride, -gx * gscale);
   }
   l = wave_sum(l);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;

@@ -73,7 +73,7 @@ class TrainStep:
         self.D_mod._weights_gen += 1
 
     def _gl(self, like):
-        return ops.new_act(like.N, like.H, like.W, 8, self.dt, self.dev, zero=True)
+        return ops.new_act(like.N, like.H, like.W, 8, self.dt, self.dev)      # tfc_bce_relativistic writes whole 8-channel pixels (logit gradient, 7 zeros)
 
     def step(self, real_A, real_B, neg_idx=None, extra_loss_G=None, T_B=None, B_tf=None):
         """real_A, real_B: fp32 NCHW [N,3,256,256] in [-1,1] on the GPU (this rank's shard). Returns a dict of device scalars.

@@ -328,7 +328,7 @@ class DiscriminatorCore:
             ctx.raw.append(raw)
             ctx.sn.append((usn[bi], vsn[bi], sigma2) if save else None)
             cur = out
-        logits = new_act(N, cur.H, cur.W, 8, dt, dev, zero=True)
+        logits = new_act(N, cur.H, cur.W, 8, dt, dev)             # only channel 0 is ever written or read (bce: stride 8; modules: [..., 0])
         ops.patchgan_head_fwd(dt, cur, self.params["model.13.weight"], View(logits.t, 1, 0))
         ctx.p4 = cur
         return View(logits.t, 1, 0), (ctx if save else None)
