@@ -105,7 +105,8 @@ __device__ __forceinline__ int tfc_xcd_remap(int bid, int nblocks) {
 // the slot.  One thread per workgroup calls this.  Slots are per-kernel __device__ globals: launches of the SAME kernel on
 // the same device must be stream-ordered (they are: one stream per engine).
 struct TfcRedSlot { double acc; unsigned cnt; unsigned pad; };
-__device__ __forceinline__ void tfc_block_commit(TfcRedSlot* slot, double partial, float* out) {
+// `set`: the last arriver STORES the total (out[0] = total) instead of adding it, so the caller needs no memset launch in front of the kernel
+__device__ __forceinline__ void tfc_block_commit(TfcRedSlot* slot, double partial, float* out, bool set = false) {
   atomicAdd(&slot->acc, partial);
   __threadfence();
   const unsigned t = atomicAdd(&slot->cnt, 1u);
@@ -114,6 +115,6 @@ __device__ __forceinline__ void tfc_block_commit(TfcRedSlot* slot, double partia
     const double tot = atomicAdd(&slot->acc, 0.0);
     atomicExch(reinterpret_cast<unsigned long long*>(&slot->acc), 0ull);
     atomicExch(&slot->cnt, 0u);
-    out[0] += (float)tot;
+    out[0] = set ? (float)tot : out[0] + (float)tot;
   }
 }

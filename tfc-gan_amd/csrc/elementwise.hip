@@ -952,6 +952,7 @@ hipError_t tfc_launch_sn_step_batched(const SnBatch& b, float* ws_t, size_t t_by
 }
 
 // spectral-norm backward: gw = (G - (sum G*Wsn) u v^T) / sigma, Wsn = W/sigma.  pass 1: dot += sum G*W ; pass 2: apply
+static __device__ TfcRedSlot g_dot_slot;
 __global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* out) {
   __shared__ float red[4];
   float s = 0.f;
@@ -968,7 +969,7 @@ __global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ 
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) tfc_block_commit(&g_dot_slot, (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3], out, true);   // out[0] = total: no memset launch
 }
 __global__ void __launch_bounds__(256) tfc_sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
                                                                 const float* __restrict__ sigma2, const float* __restrict__ gw_dot,
@@ -1025,7 +1026,7 @@ tfc_bce_rel_kernel(const T* __restrict__ a, const T* __restrict__ b, int n, int 
   l = wave_sum(l);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
   __syncthreads();
-  if (threadIdx.x == 0) tfc_block_commit(&g_bce_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (double)n, loss);
+  if (threadIdx.x == 0) tfc_block_commit(&g_bce_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (double)n, loss, true);
 }
 
 // Adam (torch.optim.Adam defaults: no weight decay, no amsgrad; reference :461-462)
@@ -1272,8 +1273,6 @@ hipError_t tfc_launch_sn_step(const float* W, float* u, float* v, float* sigma2,
 // gout = (G - (sum G*W)/sigma * u v^T)/sigma ; dot_ws: 1 float scratch
 hipError_t tfc_launch_sn_bwd(const float* G, const float* W, const float* u, const float* v, const float* sigma2, float* dot_ws,
                              float* gout, int R, int K, int accumulate, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(dot_ws, 0, sizeof(float), st);
-  if (e != hipSuccess) return e;
   const long long n = (long long)R * K;
   int nb = (int)((n + 1023) / 1024);
   if (nb > 128) nb = 128;                                        // every workgroup ends in ONE atomic on the same address (~12 ns each, serialised)
@@ -1282,8 +1281,6 @@ hipError_t tfc_launch_sn_bwd(const float* G, const float* W, const float* u, con
   return hipGetLastError();
 }
 hipError_t tfc_launch_bce_rel(int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode, float* loss, void* da, void* db, float gscale, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-  if (e != hipSuccess) return e;
   int nb = (n + 255) / 256;
   if (nb > 256) nb = 256;
   if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_bce_rel_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, n, stride, t1, t2, mode, loss, (bf16_t*)da, (bf16_t*)db, gscale);

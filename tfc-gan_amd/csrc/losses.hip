@@ -68,7 +68,7 @@ tfc_triplet16_kernel(const float* __restrict__ fake, const float* __restrict__ r
   if (lane == 0) red[w] = lsum;
   __syncthreads();
   if (threadIdx.x == 0)
-    tfc_block_commit(&g_trip_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (16.0 * N * C * 64.0), loss);
+    tfc_block_commit(&g_trip_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (16.0 * N * C * 64.0), loss, true);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -230,7 +230,7 @@ tfc_row_triplet_kernel(const float* __restrict__ a, const float* __restrict__ p,
   if (lane == 0) red[w] = lsum;
   __syncthreads();
   if (threadIdx.x == 0)
-    tfc_block_commit(&g_rowtrip_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (double)rows, loss);
+    tfc_block_commit(&g_rowtrip_slot, ((double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]) / (double)rows, loss, true);
 }
 hipError_t tfc_launch_vectorize_temps(const float* x, long long bs, int rs, int N, int H, int W, const float* lut, float* out, hipStream_t st) {
   const long long total = (long long)N * H * W;
@@ -241,9 +241,7 @@ hipError_t tfc_launch_vectorize_temps(const float* x, long long bs, int rs, int 
 }
 hipError_t tfc_launch_row_triplet(const float* a, const float* p, const float* ng, long long rows, int W, float margin, float eps,
                                   float* loss, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-  if (e != hipSuccess) return e;
-  long long nb = (rows + 3) / 4;
+  long long nb = (rows + 3) / 4;                                  // the last workgroup to arrive STORES the mean (tfc_block_commit set): no memset launch
   if (nb > 512) nb = 512;
   hipLaunchKernelGGL(tfc_row_triplet_kernel, dim3((int)nb), dim3(256), 0, st, a, p, ng, rows, W, margin, eps, loss);
   return hipGetLastError();
@@ -254,8 +252,6 @@ hipError_t tfc_launch_triplet16(const float* fake, const float* real, const int*
                                 float* loss, float* dfake, float gscale, hipStream_t st) {
   NegIdx ni;
   for (int i = 0; i < 16; ++i) ni.r[i] = neg_idx[i];
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-  if (e != hipSuccess) return e;
   long long nrows = (long long)N * C * 1024;
   long long nb = (nrows + 3) / 4;
   if (nb > 512) nb = 512;                                        // one double atomic + one ticket per workgroup on a single address
