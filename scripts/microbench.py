@@ -126,13 +126,16 @@ if "wgrad" in which:
 torch.cuda.synchronize()
 print("done")
 if "cfg4" in which:
+    # probe of a 128-pixel x 256-channel workgroup tile (wave = 128 x 64; needs a library built with -DTFC_PROBE_W64) against <4,1,1,4>
     import time
     lib = T._lib.load()
-    shapes = [(128, 64, 128), (64, 128, 256), (32, 256, 512)]
+    shapes = [(64, 128, 256), (32, 256, 512), (16, 512, 512)]
     for H, Cin, Cout in shapes:
-        x = rnd(N, H, H, Cin); w = torch.randn(Cout, Cin, 4, 4, device=DEV) * 0.03; y = ops.new_act(N, H - 1, H - 1, Cout, dt, DEV)
+        x = rnd(N, H, H, Cin); w = torch.randn(Cout, Cin, 4, 4, device=DEV) * 0.03
         pk = ops.pack_weight(dt, ops.OP_CONV, 0, w, Cin, Cout)
-        for cfg in (0, 4):
+        ys = {}
+        for cfg in (3, 4):
+            y = ops.new_act(N, H - 1, H - 1, Cout, dt, DEV)
             lib.tfc_debug_set_igemm_config(cfg)
             for _ in range(2):
                 ops.conv_fwd(dt, ops.OP_CONV, x, Cin, Cout, pk, y)
@@ -141,7 +144,9 @@ if "cfg4" in which:
                 ops.conv_fwd(dt, ops.OP_CONV, x, Cin, Cout, pk, y)
             torch.cuda.synchronize(); dtm = (time.perf_counter() - t0) / 10
             fl = 2.0 * N * (H - 1) ** 2 * Cin * Cout * 16
-            print(f"H={H} {Cin}->{Cout} cfg {cfg}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s")
+            ys[cfg] = y.t.float()
+            print(f"H={H} {Cin}->{Cout} cfg {cfg}: {dtm*1e6:7.1f} us  {fl/dtm/1e12:7.1f} TFLOP/s", flush=True)
+        print("   max |cfg4 - cfg3| =", (ys[3] - ys[4]).abs().max().item(), flush=True)
     lib.tfc_debug_set_igemm_config(-1)
 if "overlap" in which:
     # do two latency-bound MFMA kernels co-run faster than back to back? conv fwd/dgrad chain on one stream, wgrad on another

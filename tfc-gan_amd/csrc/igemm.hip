@@ -438,8 +438,15 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   static_assert(BD <= TFC_WPAD, "the packed stream carries TFC_WPAD slack k-substeps for the ring's read-ahead");
   static_assert((ROWS * NSR) % BD == 0, "register ring must realign every stage");
   constexpr int BN = 32 * NT * WN;
-  constexpr int ROWP = BN * 2 + 16;                              // staged tile: bytes per pixel row (pitch = 4 banks mod 32)
-  constexpr int UPR = BN / 8;                                    // 16-byte units per pixel row
+  // 256-channel workgroup tile (a wave owns 128 pixels x 64 channels: half the LDS operand traffic per MFMA of <4,1,1,4>): wave wn owns the
+  // 32-channel blocks {wn, wn + WN, ...} (INTERLEAVED, so that every wave takes part in each 128-channel pass of the epilogue) and the
+  // staged tile holds one 128-channel pass at a time (77 KB of LDS per workgroup: two workgroups per CU)
+  constexpr bool IL = BN > 128;
+  constexpr int NPASS = IL ? NT : 1;                             // epilogue passes of BNS channels
+  constexpr int BNS = IL ? 32 * WN : BN;
+  constexpr int ROWP = BNS * 2 + 16;                             // staged tile: bytes per pixel row (pitch = 4 banks mod 32)
+  constexpr int UPR = BNS / 8;                                   // 16-byte units per pixel row
+  constexpr int BSTEP = IL ? WN * 1024 : 1024;                   // byte distance of a wave's consecutive weight fragments in the stream
   float* out_nchw = dbg;                                         // TFC_STAMP_AT writes here in the diagnostic build
   (void)out_nchw;
 
@@ -460,12 +467,17 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 
   const int nchunks = (d.Cin_pad * 2) / 64;
   const int nst = nchunks * d.nplanes;
-  unsigned char* stage = smem + 2 * buf_bytes;
-  float* sstat = reinterpret_cast<float*>(stage + 128 * ROWP);   // [2][BN][2] statistics partials of the current / the previous tile (zero when unused)
+  // LDS map.  Narrow tiles: [halo 0 | halo 1 | staged tile | statistics | bias].  256-channel tile: [halo 0 | X | halo 1 | statistics | bias] -- the
+  // staged tile of the epilogue OVERLAYS the halo buffer the K loop has just consumed plus the gap X (the other one already holds the next
+  // tile's first chunk): [halo 0 | X] or [X | halo 1], 62 KB per workgroup instead of 83 KB, i.e. two workgroups per CU.
+  const int xtra = IL ? (128 * ROWP > buf_bytes ? 128 * ROWP - buf_bytes : 0) : 0;
+  const int bstride = buf_bytes + xtra;                          // distance of the two halo buffers
+  unsigned char* stage_fix = smem + 2 * buf_bytes;
+  float* sstat = reinterpret_cast<float*>(IL ? smem + 2 * buf_bytes + xtra : stage_fix + 128 * ROWP);   // [2][BN][2] statistics partials of the current / the previous tile (zero when unused)
   float* sbias = sstat + 4 * BN;                                 // bias of EVERY output channel of the layer (nblkN * BN floats), loaded once
 
   const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * 80 + h * 16;
-  const unsigned lanepart = (unsigned)((wn * NT) * 64 + lane) * 16u;
+  const unsigned lanepart = (unsigned)((IL ? wn : wn * NT) * 64 + lane) * 16u;
   const size_t wstep_b = (size_t)NB32 * 1024;
   const float osc = oscale ? *oscale : 1.f;
 
@@ -532,10 +544,15 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   auto loadB = [&](const unsigned char* p, u32x4_t (&b)[NT]) {    // p: this lane's address of the fragment of n-block 0
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if (nt == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[0]) : "v"(p) : "memory");
-      if (nt == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(b[1]) : "v"(p) : "memory");
-      if (nt == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(b[2]) : "v"(p) : "memory");
-      if (nt == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(b[3]) : "v"(p) : "memory");
+      if constexpr (IL) {
+        const unsigned char* pn = p + nt * BSTEP;                 // 4096 does not fit the instruction's 13-bit signed offset
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[nt]) : "v"(pn) : "memory");
+      } else {
+        if (nt == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b[0]) : "v"(p) : "memory");
+        if (nt == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(b[1]) : "v"(p) : "memory");
+        if (nt == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(b[2]) : "v"(p) : "memory");
+        if (nt == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(b[3]) : "v"(p) : "memory");
+      }
     }
   };
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(unsigned char, smem);   // LDS byte address of the dynamic region
@@ -624,9 +641,9 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 #ifdef TFC_STAMP
       TFC_NOW(tq1); acc_h += tq1 - tq0;
 #endif
-      const unsigned abase = lds0 + (sc & 1) * buf_bytes + laneBase;
+      const unsigned abase = lds0 + (sc & 1) * bstride + laneBase;
       constexpr int Q = ROWS * NSR;                               // k-substeps of one stage, one straight-line pipeline
-      u32x4_t a[2][MT];
+      u32x4_t a[IL ? 1 : 2][MT];                                  // IL: ONE set, each fragment re-requested right after its last MFMA (16 VGPRs less)
       tfc_static_for<0, MT>([&](auto mic) {
         constexpr int mi = decltype(mic)::value;
         lds_rd<(TapPat<PAT>::dy(0) * P + TapPat<PAT>::dx(0)) * 80 + mi * (2 * P * 80)>(a[0][mi], abase);
@@ -637,6 +654,38 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 #endif
       tfc_static_for<0, Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
+        if constexpr (IL) {
+          // 256-channel tile: pixel-fragment-major MFMA order (mi, nt) -- a[mi] is free after its NT MFMAs and is re-requested for k-substep
+          // q + 1 into the same registers, six MFMAs ahead of its next use.  LDS returns in order: before the MFMAs of fragment mi exactly the
+          // MT - 1 younger requests may be outstanding (fewer in the last k-substep of a stage, which requests nothing).
+          if constexpr (q < BD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * NT + 4) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * NT) : "memory");
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[q % BD][nt]));
+          if constexpr (q + BD == Q) { if (last && has_next) bptr = nxt.wbase + lanepart; }
+          tfc_static_for<0, MT>([&](auto mc) {
+            constexpr int mi = decltype(mc)::value;
+            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(q + 1 < Q ? MT - 1 : MT - 1 - mi) : "memory");
+            asm volatile("" : "+v"(a[0][mi]));
+            tfc_static_for<0, NT>([&](auto nc) {
+              constexpr int nt = decltype(nc)::value;
+              acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, br[q % BD][nt]),
+                                                                    __builtin_bit_cast(bf16x8_t, a[0][mi]), acc[mi][nt], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (nt == NT - 1 && q + 1 < Q) {
+                constexpr int r1 = (q + 1) / NSR, s1 = (q + 1) % NSR;
+                constexpr int off = (TapPat<PAT>::dy(r1) * P + TapPat<PAT>::dx(s1 >> 1)) * 80 + (s1 & 1) * 32;
+                lds_rd<off + mi * (2 * P * 80)>(a[0][mi], abase);
+              }
+              if constexpr (mi == MT - 1) {                       // br[q % BD][nt] has fed its last MFMA: request the fragment BD k-substeps ahead
+                const unsigned char* pn = bptr + nt * BSTEP;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(br[q % BD][nt]) : "v"(pn) : "memory");
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            });
+          });
+          bptr += wstep_b;
+        } else {
         // operands of this k-substep.  A(q) was requested during k-substep q - 1 (nothing younger on the LDS queue); of the weight loads
         // (BD - 1) * NT are younger than B(q), plus -- during the first BD k-substeps of a stage -- the four halo loads issued at its start
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -679,13 +728,14 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
           if constexpr (i == MT * NT - 1) bptr += wstep_b;
           __builtin_amdgcn_sched_barrier(0);
         });
+        }
       });
       // the halo loads are older than every weight load of this stage: with at most BD * NT vector-memory operations left they have landed
 #ifdef TFC_STAMP
       TFC_NOW(ts0);
 #endif
       asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BD * NT) : "memory");
-      if (more) halo_store(smem + ((sc + 1) & 1) * buf_bytes);
+      if (more) halo_store(smem + ((sc + 1) & 1) * bstride);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #ifdef TFC_STAMP
@@ -700,12 +750,18 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 #ifdef TFC_STAMP
     TFC_NOW(tk1); acc_main += tk1 - tk0; tk0 = tk1; ++ntile;
 #endif
+    unsigned char* stage = IL ? smem + ((sc & 1) ? 0 : buf_bytes) : stage_fix;   // IL: beside the live halo buffer (parity sc & 1 after the last stage)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {                          // one pass per BNS staged channels (a single pass unless the tile is 256 wide)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      if (IL && nt != ps) continue;
+      const int blk = IL ? nt * WN + wn : wn * NT + nt;           // this accumulator's 32-channel block inside the n-block ...
+      const int col = IL ? wn : wn * NT + nt;                     // ... and inside the staged pass
       float4 bq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        bq[q] = (flags & TFC_EP_BIAS) ? *reinterpret_cast<const float4*>(sbias + cur.nb_blk * BN + (wn * NT + nt) * 32 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bq[q] = (flags & TFC_EP_BIAS) ? *reinterpret_cast<const float4*>(sbias + cur.nb_blk * BN + blk * 32 + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         uint32_t pk[4][2];
@@ -725,30 +781,34 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
           auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
           auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
           const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-          *reinterpret_cast<uint4*>(stage + rho * ROWP + ((wn * NT + nt) * 32 + pr * 16 + h * 8) * 2) = o;
+          *reinterpret_cast<uint4*>(stage + rho * ROWP + (col * 32 + pr * 16 + h * 8) * 2) = o;
         }
       }
     }
-    TFC_STAMP_AT(3);
+    if (ps == 0) {
+      TFC_STAMP_AT(3);
 #ifdef TFC_STAMP
-    TFC_NOW(tk1); acc_ep1 += tk1 - tk0; tk0 = tk1;
+      TFC_NOW(tk1); acc_ep1 += tk1 - tk0; tk0 = tk1;
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the next tile's first weight fragments (requested ~2.5k cycles ago) land BEFORE the stores below
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile's first weight fragments (requested ~2.5k cycles ago) land BEFORE the stores below
 #pragma unroll
-    for (int i = 0; i < BD; ++i)
+      for (int i = 0; i < BD; ++i)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[i][nt]));
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[i][nt]));
+    }
     __syncthreads();
-    TFC_STAMP_AT(4);
+    if (ps == 0) {
+      TFC_STAMP_AT(4);
 #ifdef TFC_STAMP
-    TFC_NOW(tk1); acc_bar += tk1 - tk0; tk0 = tk1;
+      TFC_NOW(tk1); acc_bar += tk1 - tk0; tk0 = tk1;
 #endif
+    }
     {
-      const int n0 = cur.nb_blk * BN + su * 8;
+      const int n0 = cur.nb_blk * BN + ps * BNS + su * 8;
       const int ylim = d.GH - cur.a0, xlim = d.GW - cur.b0;
       // wave-uniform part of the output address of this tile (the per-thread part srel[k] is tile-invariant)
       bf16_t* obase = out + ((long long)(cur.img * d.OH + cur.a0 * d.OS + d.OOY + cur.phy * d.ph_oo) * d.OW + cur.b0 * d.OS + d.OOX + cur.phx * d.ph_oo) * d.out_pitch +
-                      cur.nb_blk * BN;
+                      cur.nb_blk * BN + ps * BNS;
       float s1[8], s2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -787,13 +847,15 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
           for (int o = 32; o >= UPR; o >>= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
         }
         if (lane < UPR) {
-          float* sp = sstat + (tcount & 1) * 2 * BN;
+          float* sp = sstat + (tcount & 1) * 2 * BN + ps * 2 * BNS;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { atomicAdd(&sp[(su * 8 + e) * 2], s1[e]); atomicAdd(&sp[(su * 8 + e) * 2 + 1], s2[e]); }
         }
         stat_prev = stats + ((size_t)cur.img * d.Nout + cur.nb_blk * BN) * 2;
         stat_lim = 2 * (d.Nout - cur.nb_blk * BN);                // floats of this n-block that exist
       }
+    }
+    if (IL) __syncthreads();                                      // the staged tile is rewritten by the next pass / by the next tile's first halo store
     }
     ++tcount;
     TFC_STAMP_AT(5);
@@ -2846,7 +2908,10 @@ static hipError_t launch_igemm2_pat(const TfcGather& d, const void* in, const vo
   for (int pl = 0; pl < d.nplanes; ++pl) maxhh = d.plane[pl].hh > maxhh ? d.plane[pl].hh : maxhh;
   const int buf_bytes = maxhh * TFC_LDS_P * 80;
   constexpr int BN = 32 * NT * WN;
-  const int lds = 2 * buf_bytes + 128 * (BN * 2 + 16) + 4 * BN * 4 + nblkN * BN * 4;   // halo x 2 | staged tile | statistics x 2 | bias table
+  constexpr int BNS = BN > 128 ? 32 * WN : BN;                    // channels of one staged epilogue pass
+  constexpr int STG = 128 * (BNS * 2 + 16);
+  // 256-channel tile: the staged tile overlays a consumed halo buffer (see the kernel's LDS map)
+  const int lds = (BN > 128 ? 2 * buf_bytes + (STG > buf_bytes ? STG - buf_bytes : 0) : 2 * buf_bytes + STG) + 4 * BN * 4 + nblkN * BN * 4;   // halo x 2 | staged tile | statistics x 2 | bias table
   const int nwork = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1) * nblkN;
   // resident workgroups per CU of THIS instantiation (2 for the 128-channel tile: 77 KB of LDS, ~195 VGPRs; 3 for the narrower tiles); a persistent
   // grid never depends on co-residency for correctness (no inter-workgroup waits), so the occupancy query only sizes the grid
@@ -2923,6 +2988,11 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
       return hipGetLastError();
     }
   }
+#ifdef TFC_PROBE_W64
+  if constexpr (sizeof(T) == 2) {
+    if (fcfg == 4 && nb >= 8) return launch_igemm2_cfg<4, 2, 1, 4>(match_pattern(d, 2), d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  }
+#endif
   if (fcfg == 3 && nb >= 4) return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if (fcfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
   if ((fcfg == 0 || fcfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
