@@ -696,6 +696,12 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[q % BD][nt]));
         if constexpr (q + BD == Q) { if (last && has_next) bptr = nxt.wbase + lanepart; }
+#ifndef TFC_ABL_HS_END
+        // the next stage's halo goes to LDS HERE, not at the end of the stage: the four halo loads are older than B(q) for q >= BD, so the wait above has
+        // landed them; the buffer they go to was last read a stage ago (behind that stage's barrier).  The end of the stage is then a bare s_barrier instead of
+        // wait -> 4 x ds_write_b128 -> lgkmcnt(0) -> barrier in series (~0.6 k cycles per stage, 15 % of a 128-MFMA stage).
+        if constexpr (Q > BD && q == BD) { if (more) halo_store(smem + ((sc + 1) & 1) * bstride); }
+#endif
         // One wave issues in order: memory instructions bunched behind the last MFMA of a k-substep all land in ONE 32-cycle MFMA gap and overrun
         // it (measured: ~60 idle matrix-pipe cycles per k-substep for a wave alone on its SIMD).  They are therefore dealt out over the gaps,
         // at most two per gap, and the order is pinned with sched_barrier (the MFMAs are builtins: nothing else keeps hipcc from re-bunching):
@@ -734,8 +740,15 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 #ifdef TFC_STAMP
       TFC_NOW(ts0);
 #endif
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BD * NT) : "memory");
-      if (more) halo_store(smem + ((sc + 1) & 1) * bstride);
+#ifndef TFC_ABL_HS_END
+      constexpr bool HS_MID = !IL && Q > BD;                      // halo already stored inside the K loop (see there)
+#else
+      constexpr bool HS_MID = false;
+#endif
+      if constexpr (!HS_MID) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BD * NT) : "memory");
+        if (more) halo_store(smem + ((sc + 1) & 1) * bstride);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #ifdef TFC_STAMP
