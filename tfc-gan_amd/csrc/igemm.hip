@@ -688,9 +688,16 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
         } else {
         // operands of this k-substep.  A(q) was requested during k-substep q - 1 (nothing younger on the LDS queue); of the weight loads
         // (BD - 1) * NT are younger than B(q), plus -- during the first BD k-substeps of a stage -- the four halo loads issued at its start
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef TFC_ABL_LGKM0
+        constexpr bool CNT_LGKM = false;
+#else
+        constexpr bool CNT_LGKM = NT == 1;                        // counted per-fragment LDS waits (below); measured worse for the two-fragment tiles
+#endif
+        if constexpr (!CNT_LGKM) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(a[q & 1][mi]));
+          for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(a[q & 1][mi]));
+        }
         if constexpr (q < BD) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * NT + 4) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((BD - 1) * NT) : "memory");
 #pragma unroll
@@ -709,6 +716,16 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
         //   the weight fragment of n-block nt BD k-substeps ahead (its register is free from here on)
         tfc_static_for<0, MT * NT>([&](auto ic) {
           constexpr int i = decltype(ic)::value, nt = i / MT, mi = i % MT;
+          // COUNTED LDS wait: fragment mi of this k-substep was requested one k-substep ago (behind MFMA mi of k-substep q - 1) and LDS returns in order;
+          // behind it exactly MT - 1 younger fragment reads exist (the rest of its own k-substep + the first mi of the next one) -- fewer in the last
+          // k-substep of a stage, which requests nothing.  (lgkmcnt(0) at the top of the k-substep waited for the fragment requested a few cycles
+          // earlier: a full LDS round trip exposed per k-substep.)  Other LDS traffic (the mid-stage halo store) is younger and only lengthens the wait.
+          if constexpr (CNT_LGKM && nt == 0) {
+            constexpr int per0 = (MT + MT * NT - 1) / (MT * NT);                         // fragment reads per gap (see below)
+            constexpr int younger = q + 1 < Q ? (per0 == 1 ? MT - 1 : MT - per0) : MT - 1 - mi;
+            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(younger < 0 ? 0 : younger) : "memory");
+            asm volatile("" : "+v"(a[q & 1][mi]));
+          }
           acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, br[q % BD][nt]),      // swapped operands: rows =
                                                                 __builtin_bit_cast(bf16x8_t, a[q & 1][mi]), acc[mi][nt], 0, 0, 0);   // channels, lanes = pixels
           __builtin_amdgcn_sched_barrier(0);
