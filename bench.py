@@ -181,12 +181,20 @@ def main():
     # stream. An event pair costs ~2.3 us of stream time (A/B in scripts/ab_prof.py: 0.45 ms per fully instrumented step, 3.5 %), so
     # every PROF_EVERY-th timed step is instrumented, not all of them: `value` then carries < 1 % of instrumentation overhead.
     t0 = time.perf_counter()
+    # The product runs its weight gradients on a second stream beside the input-gradient chain (nets.py). A launch that shares the chip with another
+    # kernel has no duration of its own, so the INSTRUMENTED steps (and only they) run everything in line on one stream: the roofline object then
+    # prices exclusive launches, `value` is the mix actually run (every PROF_EVERY-th step serial, the rest overlapped).
+    side_default = T.set_wgrad_stream(True)
+    T.set_wgrad_stream(side_default)
     for i in range(args.steps):
-        T.ops.prof_enable(i % PROF_EVERY == 0)
+        inst = i % PROF_EVERY == 0
+        T.ops.prof_enable(inst)
+        T.set_wgrad_stream(side_default and not inst)
         out = ts.step(A, B, extra_loss_G=extra)
     barrier()
     elapsed = time.perf_counter() - t0
     T.ops.prof_enable(False)
+    T.set_wgrad_stream(side_default)
     recs = T.ops.prof_records(16384)
     ig_ms, ig_flop, ig_n = T.ops.prof_collect(0)
     wg_ms, wg_flop, wg_n = T.ops.prof_collect(1)
@@ -232,6 +240,8 @@ def main():
                          "traffic": pmc_traffic(DOMINANT_KERNEL) if args.dtype == "bf16" else None, "traffic_unit": "HBM bytes per launch (PMC)", "launches": dom_launches,
                          "avg_launch_ms": dom_ms / max(dom_launches, 1), "algorithmic_gflop_per_launch": dom_flop / 1e9 / max(dom_launches, 1),
                          "instrumented_steps": nprof, "share_of_step_time": (dom_ms / 1e3 / nprof) / step_s,
+                         "instrumented_mode": ("one stream: exclusive launches (the other timed steps run the weight gradients on a second stream)"
+                                               if side_default else "one stream (TFC_WGRAD_STREAM=0: every step)"),
                          "whole_conv_class": {"kernels": "tfc_igemm2_kernel + tfc_conv_c8_kernel + 3-channel head kernels", "achieved": (ig_flop / 1e12) / (ig_ms / 1e3) if ig_ms > 0 else 0.0,
                                               "unit": "TFLOP/s", "calls": ig_n, "share_of_step_time": (ig_ms / 1e3 / nprof) / step_s},
                          "second_kernel": {"kernel": "tfc_wgrad_kernel family (incl. slab reduction)", "achieved": (wg_flop / 1e12) / (wg_ms / 1e3) if wg_ms > 0 else 0.0,

@@ -14,7 +14,7 @@ rows = list(csv.DictReader(open(stats)))
 steps = 7
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(f"profiles/{tag}_bench_n1_kernel_stats.md", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (MI355X, batch 32, bf16; 7 steps incl. warm-up)\n\n```\n")
+    f.write("# TFC_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (MI355X, batch 32, bf16; 7 steps incl. warm-up; one stream, so that a traced duration is kernel time -- the product default overlaps the weight gradients on a second stream)\n\n```\n")
     f.write(f"total {tot / 1e6 / steps:.3f} ms/step over {steps} steps\n")
     for r in rows[:60]:
         f.write(f"{r['Name'][:100]:100s} {int(r['Calls']) / steps:6.1f}/step {float(r['TotalDurationNs']) / 1e6 / steps:7.3f} ms "

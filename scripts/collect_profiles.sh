@@ -7,6 +7,9 @@ tag=$1
 o=gpurun_out/${tag}_prof
 mkdir -p $o
 # 1. kernel trace + stats of the bench command (7 steps incl. warm-up), joined with the launch log for the per-layer table
+#    TFC_WGRAD_STREAM=0: every launch alone on the chip, so that a traced duration is kernel time (the product overlaps the weight gradients with the
+#    input-gradient chain on a second stream; bench.py's instrumented steps serialise the same way). The un-profiled run (3.) uses the product default.
+export TFC_WGRAD_STREAM=0
 rm -f $o/launch.log
 export TFC_LAUNCH_LOG=$PWD/$o/launch.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace -o p -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $o/bench_traced.json 2> $o/bench_traced.err
@@ -20,6 +23,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc/write -o
 echo "write done"
 python3 scripts/pmc_traffic.py $o/pmc $o/pmc_traffic.json | head -8
 # 3. the un-profiled default run
+unset TFC_WGRAD_STREAM
 python3 bench.py > $o/bench.json 2> $o/bench.err
 cut -c1-300 $o/bench.json
 # the raw counter CSVs are large: keep the summaries only

@@ -237,6 +237,36 @@ def test_full_size_properties_batch32():
     assert z.item() == 0.0
 
 
+@pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
+def test_wgrad_side_stream_same_gradients(cdt):
+    """nets.py runs the weight gradients on a second stream beside the input-gradient chain (product default). One step with and without it, from the
+    same weights and inputs, must produce the same parameter gradients up to the run-to-run spread of the float atomics upstream (InstanceNorm sums,
+    loss sums): a missing dependency or a temporary handed back to the allocator too early would show as a gross error."""
+    T.set_compute_dtype(cdt)
+    grads = []
+    prev = T.set_wgrad_stream(True)
+    try:
+        for on in (True, False):
+            T.set_wgrad_stream(on)
+            G = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=71).to(DEV)
+            D = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=72).to(DEV)
+            A, B = O.synthetic_pairs(2, seed=73)
+            A, B = A.to(DEV), B.to(DEV)
+            ts = T.TrainStep(G, D, compute_dtype=cdt)
+            ts.step(A, B)
+            torch.cuda.synchronize()
+            grads.append((ts.gflat.grad.clone(), ts.dflat.grad.clone()))
+    finally:
+        T.set_wgrad_stream(prev)
+        T.set_compute_dtype(torch.float32)
+    # measured spread between two runs of the SAME setting (scripts/side_stream_check.py: float atomics upstream): fp32 cos 0.999996 / 1.000000 (G / D),
+    # bf16 0.991 / 0.999995 -- the on-vs-off figures are the same numbers
+    for (g1, g0), lim in zip(zip(*grads), ((0.9999, 0.97), (0.99999, 0.9995))):
+        assert torch.isfinite(g1).all() and g0.abs().max().item() > 0
+        cos = F.cosine_similarity(g1.double(), g0.double(), dim=0).item()
+        assert cos > (lim[0] if cdt == torch.float32 else lim[1]), cos
+
+
 def test_module_forward_sees_weights_updated_by_trainstep():
     """the module's operand-stream cache is keyed on (data_ptr, _version); the raw-pointer Adam kernel moves neither.
     G(x); ts.step(); G(x) must equal a FRESH module loaded from the same state_dict (P16:395 sample_images calls generator(real_A)

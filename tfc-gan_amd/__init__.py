@@ -10,6 +10,7 @@ FFT_Components / fft_components / calculate_ffts, and the fused TrainStep + data
 from . import _lib, data, engine, inference, losses, lpips, models, nets, ops, parallel, stn, stn21, synthetic  # noqa: F401
 from ._lib import TfcError, build  # noqa: F401
 from .engine import TrainStep  # noqa: F401
+from .nets import set_wgrad_stream  # noqa: F401
 from .data import DeviceLoader, ImageDataset, TestImageDataset, pair_resize_normalize  # noqa: F401
 from .lpips import LPIPS  # noqa: F401
 from .stn21 import STN21Step  # noqa: F401

@@ -9,10 +9,52 @@ the down path writes its pooled output straight into the skip window, and the tr
 buffer (reference torch.cat, :133).  Gradients mirror that: the convT dgrad writes the whole concat gradient, the
 down path accumulates into its window.
 """
+import os
+
 import torch
 
 from . import ops
 from .ops import (DT_BF16, OP_CONV, OP_CONVT, OP_PADCONV, OP_UPCONV, View, new_act)
+
+# Weight gradients on a second HIP stream. The weight gradient of layer i needs only the gradient of its output, which the main chain (input gradient ->
+# activation backward -> next layer) has finished with, so it runs beside that chain and fills the tails of its persistent launches (same-box A/B:
+# 10.22 -> 10.05 ms per step). Everything that touches a layer's parameter gradients (wgrad, spectral-norm backward, bias column sum, the all-reduce
+# hook) stays together on the side stream, in program order; backward() joins before it returns. Results are bit-identical either way (no atomics
+# cross the streams). TFC_WGRAD_STREAM=0 or set_wgrad_stream(False) serialises everything on the caller's stream (bench.py does that in its
+# instrumented steps, so that a launch's duration is kernel time).
+_SIDE = {"on": os.environ.get("TFC_WGRAD_STREAM", "1") not in ("", "0"), "streams": {}}
+
+
+def set_wgrad_stream(on):
+    """weight gradients on a second stream (default) or in line on the caller's stream; returns the previous setting"""
+    prev, _SIDE["on"] = _SIDE["on"], bool(on)
+    return prev
+
+
+def _side_stream(dev):
+    st = _SIDE["streams"].get(dev)
+    if st is None:
+        st = _SIDE["streams"][dev] = torch.cuda.Stream(dev)
+    return st
+
+
+def _on_side(dev, fn, *tensors):
+    """run fn() on the side stream behind everything queued on the current stream so far; `tensors` are temporaries fn reads that the caller drops
+    before the join (the caching allocator must not hand them out again until the side stream is done with them)"""
+    if not _SIDE["on"]:
+        return fn()
+    cur, st = torch.cuda.current_stream(dev), _side_stream(dev)
+    st.wait_stream(cur)
+    with torch.cuda.stream(st):
+        out = fn()
+    for t in tensors:
+        (t.t if isinstance(t, View) else t).record_stream(st)
+    return out
+
+
+def _join_side(dev):
+    if _SIDE["on"]:
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
 
 # (name, Cin, Cout, normalize, dropout)  -- reference :140-145
 G_DOWN = [("down1", 3, 64, False, 0.0), ("down2", 64, 128, True, 0.0), ("down3", 128, 256, True, 0.5),
@@ -161,6 +203,12 @@ class GeneratorCore:
 
     # ---- backward ----
     def backward(self, ctx, g_fake, grads, hook=None, accumulate=False, need_input_grad=False):
+        try:
+            return self._backward(ctx, g_fake, grads, hook, accumulate, need_input_grad)
+        finally:
+            _join_side(g_fake.device)                             # the weight gradients may have run on the side stream
+
+    def _backward(self, ctx, g_fake, grads, hook=None, accumulate=False, need_input_grad=False):
         """g_fake: fp32 NCHW gradient of the loss wrt fake. grads: dict key -> fp32 tensor (torch layout) that receives the
         parameter gradients (overwritten, or accumulated when `accumulate`). hook(key) fires when a gradient is final.
         need_input_grad: also return d loss / d x as fp32 NCHW (STN21: fake_A2 = generator2(warped_B), STN:629 -- the warp and the localiser
@@ -172,10 +220,12 @@ class GeneratorCore:
         if not accumulate:
             gb.zero_()
         dyf = ops.tanh_bwd_pack(dt, g_fake.contiguous().float(), ctx.fake, dbias=gb)
-        self._ws = ops.conv_wgrad(dt, OP_UPCONV, ctx.u5, dyf, 128, ch, grads["final.2.weight"], accumulate, self._ws)
-        if hook:
-            hook("final.2.weight")
-            hook("final.2.bias")
+        def _head_wgrad():
+            self._ws = ops.conv_wgrad(dt, OP_UPCONV, ctx.u5, dyf, 128, ch, grads["final.2.weight"], accumulate, self._ws)
+            if hook:
+                hook("final.2.weight")
+                hook("final.2.bias")
+        _on_side(dev, _head_wgrad, dyf)
         g_cat = new_act(N, ctx.u5.H, ctx.u5.W, ctx.u5.pitch, dt, dev)
         if dt == DT_BF16 and ch <= 8 and ctx.u5.pitch == 128:
             ops.upconv_head_dgrad(dt, dyf, N, ctx.u5.H, ctx.u5.W, self.params["final.2.weight"], g_cat)    # weights-stationary head kernel
@@ -203,9 +253,11 @@ class GeneratorCore:
             if dbg is not None:
                 dbg[f"{name}.g_out"] = ops.View(g_cat.t.clone(), g_cat.C)       # gradient of the whole concat buffer (up window | skip window)
                 dbg[f"{name}.d_blur"], dbg[f"{name}.d_rawT"] = d_blur, d_rawT
-            self._ws = ops.conv_wgrad(dt, OP_CONVT, uin, d_rawT, cin, cout, grads[key], accumulate, self._ws)
-            if hook:
-                hook(key)
+            def _up_wgrad(uin=uin, d_rawT=d_rawT, cin=cin, cout=cout, key=key):
+                self._ws = ops.conv_wgrad(dt, OP_CONVT, uin, d_rawT, cin, cout, grads[key], accumulate, self._ws)
+                if hook:
+                    hook(key)
+            _on_side(dev, _up_wgrad, d_rawT)
             g_in = new_act(N, uin.H, uin.W, uin.pitch, dt, dev)
             ops.conv_dgrad(dt, OP_CONVT, d_rawT, N, uin.H, uin.W, cin, cout, self.packed[name]["dgrad"], g_in)
             if dbg is not None:
@@ -223,9 +275,11 @@ class GeneratorCore:
                     and pooled(Hc) >= 2):
                 # nothing but this weight gradient needs the 266 MB gradient of the first convolution's output: it is never written (igemm.hip:
                 # tfc_wgrad_c8_fused_kernel = tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad in one kernel, same d_raw bits)
-                self._ws = ops.first_block_bwd_wgrad(dt, din, raw, g_cur, cin, cout, grads[key], slope=0.2, accumulate=accumulate, ws=self._ws)
-                if hook:
-                    hook(key)
+                def _first_wgrad(din=din, raw=raw, g_cur=g_cur, cin=cin, cout=cout, key=key):
+                    self._ws = ops.first_block_bwd_wgrad(dt, din, raw, g_cur, cin, cout, grads[key], slope=0.2, accumulate=accumulate, ws=self._ws)
+                    if hook:
+                        hook(key)
+                _on_side(dev, _first_wgrad, g_cur)
                 continue
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             if normalize:
@@ -238,9 +292,11 @@ class GeneratorCore:
             if dbg is not None:
                 dbg[f"{name}.g_out"] = ops.View(g_cur.t[..., g_cur.coff:g_cur.coff + g_cur.C].clone(), g_cur.C)   # incl. the accumulated skip part
                 dbg[f"{name}.d_raw"] = d_raw
-            self._ws = ops.conv_wgrad(dt, OP_CONV, din, d_raw, cin, cout, grads[key], accumulate, self._ws)
-            if hook:
-                hook(key)
+            def _down_wgrad(din=din, d_raw=d_raw, cin=cin, cout=cout, key=key):
+                self._ws = ops.conv_wgrad(dt, OP_CONV, din, d_raw, cin, cout, grads[key], accumulate, self._ws)
+                if hook:
+                    hook(key)
+            _on_side(dev, _down_wgrad, d_raw)
             if i > 0:
                 tgt = g_skip[i - 1]                               # window of d_{i} gradient already holding the skip-path part
                 ops.conv_dgrad(dt, OP_CONV, d_raw, N, din.H, din.W, cin, cout, self.packed[name]["dgrad"], tgt, accumulate=True)
@@ -334,16 +390,24 @@ class DiscriminatorCore:
         return View(logits.t, 1, 0), (ctx if save else None)
 
     def backward(self, ctx, g_logits, grads=None, need_input_grad=True, accumulate=False, hook=None, ws=None):
+        try:
+            return self._backward(ctx, g_logits, grads, need_input_grad, accumulate, hook, ws)
+        finally:
+            _join_side(g_logits.t.device)                         # the weight gradients may have run on the side stream
+
+    def _backward(self, ctx, g_logits, grads=None, need_input_grad=True, accumulate=False, hook=None, ws=None):
         """g_logits: View [N,h,w,8] (channel 0 = gradient, channels 1..7 zero). grads: dict key -> fp32 tensor or None
         (skip all weight gradients: generator step). Returns fp32 NCHW gradient of img_a (first argument) or None."""
         dt, N = self.dt, ctx.N
         dev = g_logits.t.device
-        ws = getattr(self, "_ws", None) if ws is None else ws     # persistent wgrad scratch (zeroed once, re-zeroed by the kernels)
+        wsh = [getattr(self, "_ws", None) if ws is None else ws]  # persistent wgrad scratch (zeroed once, re-zeroed by the kernels)
         gl = View(g_logits.t, 8, 0)
         if grads is not None:
-            ws = ops.conv_wgrad(dt, OP_PADCONV, ctx.p4, gl, 512, 1, grads["model.13.weight"], accumulate, ws)
-            if hook:
-                hook("model.13.weight")
+            def _head_wgrad():
+                wsh[0] = ops.conv_wgrad(dt, OP_PADCONV, ctx.p4, gl, 512, 1, grads["model.13.weight"], accumulate, wsh[0])
+                if hook:
+                    hook("model.13.weight")
+            _on_side(dev, _head_wgrad)
         g_cur = new_act(N, ctx.p4.H, ctx.p4.W, 512, dt, dev)
         ops.conv_dgrad(dt, OP_PADCONV, gl, N, ctx.p4.H, ctx.p4.W, 512, 1, self.head_packed["dgrad"], g_cur)
         g_in = None
@@ -357,17 +421,19 @@ class DiscriminatorCore:
                     and ops.first_block_bwd_supported(dt, cin, cout))
             if fuse:
                 # discriminator step: block 1's conv-output gradient (266 MB) feeds only its weight / bias gradients -> never written
-                W = self.params[f"model.{i}.parametrizations.weight.original"]
-                gsn = torch.empty_like(W)
-                ws = ops.first_block_bwd_wgrad(dt, xin, raw, g_cur, cin, cout, gsn, slope=0.2, ws=ws, bias_sums=gb_img)
-                gbias = grads[f"model.{i}.bias"]
-                if not accumulate:
-                    gbias.zero_()
-                ops.colsum(ops.DT_F32, View(gb_img.view(N, 1, 1, cout), cout), gbias)
-                ops.spectral_norm_bwd(gsn, W, u, v, sigma2, grads[f"model.{i}.parametrizations.weight.original"], accumulate)
-                if hook:
-                    hook(f"model.{i}.parametrizations.weight.original")
-                    hook(f"model.{i}.bias")
+                def _first_wgrad(i=i, cin=cin, cout=cout, xin=xin, raw=raw, g_cur=g_cur, gb_img=gb_img, u=u, v=v, sigma2=sigma2):
+                    W = self.params[f"model.{i}.parametrizations.weight.original"]
+                    gsn = torch.empty_like(W)
+                    wsh[0] = ops.first_block_bwd_wgrad(dt, xin, raw, g_cur, cin, cout, gsn, slope=0.2, ws=wsh[0], bias_sums=gb_img)
+                    gbias = grads[f"model.{i}.bias"]
+                    if not accumulate:
+                        gbias.zero_()
+                    ops.colsum(ops.DT_F32, View(gb_img.view(N, 1, 1, cout), cout), gbias)
+                    ops.spectral_norm_bwd(gsn, W, u, v, sigma2, grads[f"model.{i}.parametrizations.weight.original"], accumulate)
+                    if hook:
+                        hook(f"model.{i}.parametrizations.weight.original")
+                        hook(f"model.{i}.bias")
+                _on_side(dev, _first_wgrad, g_cur, gb_img)
                 continue
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
@@ -376,25 +442,27 @@ class DiscriminatorCore:
                 ddbg[f"b{bi}.g_out"], ddbg[f"b{bi}.d_raw"] = g_cur, d_raw
             W = self.params[f"model.{i}.parametrizations.weight.original"]
             if grads is not None:
-                gbias = grads[f"model.{i}.bias"]
-                if not accumulate:
-                    gbias.zero_()
-                ops.colsum(ops.DT_F32, View(gb_img.view(N, 1, 1, cout), cout), gbias)
-                gsn = torch.empty_like(W)
-                ws = ops.conv_wgrad(dt, OP_CONV, xin, d_raw, cin, cout, gsn, False, ws)
-                ops.spectral_norm_bwd(gsn, W, u, v, sigma2, grads[f"model.{i}.parametrizations.weight.original"], accumulate)
-                if hook:
-                    hook(f"model.{i}.parametrizations.weight.original")
-                    hook(f"model.{i}.bias")
+                def _block_wgrad(i=i, cin=cin, cout=cout, xin=xin, d_raw=d_raw, gb_img=gb_img, W=W, u=u, v=v, sigma2=sigma2):
+                    gbias = grads[f"model.{i}.bias"]
+                    if not accumulate:
+                        gbias.zero_()
+                    ops.colsum(ops.DT_F32, View(gb_img.view(N, 1, 1, cout), cout), gbias)
+                    gsn = torch.empty_like(W)
+                    wsh[0] = ops.conv_wgrad(dt, OP_CONV, xin, d_raw, cin, cout, gsn, False, wsh[0])
+                    ops.spectral_norm_bwd(gsn, W, u, v, sigma2, grads[f"model.{i}.parametrizations.weight.original"], accumulate)
+                    if hook:
+                        hook(f"model.{i}.parametrizations.weight.original")
+                        hook(f"model.{i}.bias")
+                _on_side(dev, _block_wgrad, d_raw, gb_img)
             if bi == 0 and need_input_grad and dt == DT_BF16 and self.channels <= 4 and cout == 64:
                 # gradient w.r.t. the generated image only (3 of the 6 input channels): rows-packed 16-wide MFMA kernel, fp32 NCHW out
-                self._ws = ws
+                self._ws = wsh[0]
                 return ops.conv_dgrad_image(dt, d_raw, N, xin.H, xin.W, cin, W, sigma2[1:], self.channels)
             if bi > 0 or need_input_grad:
                 g_in = new_act(N, xin.H, xin.W, xin.pitch, dt, dev)
                 ops.conv_dgrad(dt, OP_CONV, d_raw, N, xin.H, xin.W, cin, cout, self.head_packed[f"d{i}"], g_in, oscale=sigma2[1:])
                 g_cur = g_in
-        self._ws = ws
+        self._ws = wsh[0]
         if need_input_grad:
             return ops.unpack_nchw(dt, g_cur, self.channels, c0=0)
         return None
