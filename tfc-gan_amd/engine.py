@@ -12,6 +12,7 @@ negatives `B_tf`): it adds 0.5 * loss_temp_g to the logged loss_G exactly as :60
 GradScaler (:518); the reference's wasted D weight-gradients during the G step (:619 zeroes them) are simply not computed.
 """
 import math
+import os
 
 import torch
 
@@ -93,16 +94,29 @@ class TrainStep:
             self._pversions = pv
         ops.arena_begin(self.dev)                                 # one fill for all the small zero-initialised buffers of this step
         # ---------------- generator step ----------------
-        fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
-        pf, dctx_f = self.D.forward(fake, real_A, power_iter=True, save=True)
-        pr, _ = self.D.forward(real_B, real_A, power_iter=True, save=False)
+        def pixel_losses():
+            lt, gt = ops.patch16_triplet(fake, real_B, neg_idx, want_grad=True, gscale=self.lambda_trip)
+            lf = patch_fft_loss(fake, real_B) if self.fft_mode == "patch" else global_fft_loss(fake, real_B)
+            return lt, gt, lf
+        if nets.side_stream_on() and os.environ.get("TFC_NO_GSTEP_OVERLAP", "0") in ("", "0"):
+            # Two-stream form of the same program (nets.py: side stream). Both power iterations of this step's two discriminator calls come first, in
+            # call order (they read the weights only); the chain of the SECOND call (real pair, no gradient) then runs beside the generator forward,
+            # and the triplet / FFT losses of the generated image beside the first call's chain.
+            snap_f = self.D.sn_snapshot(self.dev, True, True)
+            snap_r = self.D.sn_snapshot(self.dev, True, False)
+            pr = nets.on_side(self.dev, lambda: self.D.chain(real_B, real_A, snap_r, save=False), snap_r[2][0])[0]
+            fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
+            side_losses = nets.on_side(self.dev, pixel_losses)
+            pf, dctx_f = self.D.chain(fake, real_A, snap_f, save=True)
+            nets.join_side(self.dev)
+            loss_trip, g_trip, (loss_fft, loss_amp, loss_pha) = side_losses
+        else:
+            fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
+            pf, dctx_f = self.D.forward(fake, real_A, power_iter=True, save=True)
+            pr, _ = self.D.forward(real_B, real_A, power_iter=True, save=False)
+            loss_trip, g_trip, (loss_fft, loss_amp, loss_pha) = pixel_losses()
         g_pf = self._gl(pf)
         loss_gan = ops.bce_relativistic(dt, pf, pr, 0, 0.9, da=ops.View(g_pf.t, 1, 0), gscale=self.lambda_gan)
-        loss_trip, g_trip = ops.patch16_triplet(fake, real_B, neg_idx, want_grad=True, gscale=self.lambda_trip)
-        if self.fft_mode == "patch":
-            loss_fft, loss_amp, loss_pha = patch_fft_loss(fake, real_B)
-        else:
-            loss_fft, loss_amp, loss_pha = global_fft_loss(fake, real_B)
         g_fake = self.D.backward(dctx_f, g_pf, grads=None, need_input_grad=True)
         ops.axpby(g_fake, g_fake, g_trip, 1.0, 1.0)
         extra = None
@@ -110,12 +124,16 @@ class TrainStep:
             extra, g_extra = extra_loss_G(fake, real_B)
             ops.axpby(g_fake, g_fake, g_extra, 1.0, 1.0)
         self.G.backward(gctx, g_fake, self.gflat.grad_views, hook=self.g_reduce.ready)
-        gscale = self.g_reduce.finish()
-        ops.adam_step(self.gflat.data, self.gflat.grad, self.gm, self.gv, self.lr, self.b1, self.b2, self.eps, t, gscale)
-        self.G.repack()
+        def g_update():
+            gscale = self.g_reduce.finish()
+            ops.adam_step(self.gflat.data, self.gflat.grad, self.gm, self.gv, self.lr, self.b1, self.b2, self.eps, t, gscale)
+            self.G.repack()
+        if nets.side_stream_on() and os.environ.get("TFC_NO_GUPDATE_OVERLAP", "0") in ("", "0"):
+            nets.on_side(self.dev, g_update)                      # HBM-bound Adam + re-pack beside the discriminator step's first chain (joined by D.backward)
+        else:
+            g_update()
         # ---------------- discriminator step ----------------
-        pr2, dctx_r = self.D.forward(real_B, real_A, power_iter=True, save=True)
-        pf2, dctx_f2 = self.D.forward(fake, real_A, power_iter=True, save=True)
+        (pr2, dctx_r), (pf2, dctx_f2) = self.D.forward_pair(real_B, real_A, fake, real_A, power_iter=True, save=True)
         g_pr, g_pf2 = self._gl(pr2), self._gl(pf2)
         loss_d = ops.bce_relativistic(dt, pr2, pf2, 1, 0.9, 0.0, da=ops.View(g_pr.t, 1, 0), db=ops.View(g_pf2.t, 1, 0))
         self.D.backward(dctx_r, g_pr, grads=self.dflat.grad_views, need_input_grad=False, accumulate=False)

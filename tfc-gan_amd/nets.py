@@ -56,6 +56,14 @@ def _join_side(dev):
     if _SIDE["on"]:
         torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
 
+
+# the engine's names for the same three
+def side_stream_on():
+    return _SIDE["on"]
+
+
+on_side, join_side = _on_side, _join_side
+
 # (name, Cin, Cout, normalize, dropout)  -- reference :140-145
 G_DOWN = [("down1", 3, 64, False, 0.0), ("down2", 64, 128, True, 0.0), ("down3", 128, 256, True, 0.5),
           ("down4", 256, 512, True, 0.5), ("down5", 512, 512, False, 0.0), ("down6", 512, 512, True, 0.0)]
@@ -342,18 +350,22 @@ class DiscriminatorCore:
                 self.head_packed[key] = buf
         self._plan.run()
 
-    def forward(self, img_a, img_b, power_iter=True, save=True):
-        """img_a, img_b: fp32 NCHW [N,3,S,S]. Returns (logits View [N,S/16,S/16,pitch 8] channel 0, ctx)."""
+    def forward(self, img_a, img_b, power_iter=True, save=True, after_sn=None):
+        """img_a, img_b: fp32 NCHW [N,3,S,S]. Returns (logits View [N,S/16,S/16,pitch 8] channel 0, ctx).
+        = sn_snapshot() + chain(). after_sn: called once the power iteration of this call is queued -- everything after it reads only this call's
+        snapshots of u, v, sigma, so a second forward may start from there on another stream (forward_pair)."""
         ops.require_gpu(img_a, img_b)
+        snapshot = self.sn_snapshot(img_a.device, power_iter, save)
+        if after_sn is not None:
+            after_sn()
+        return self.chain(img_a, img_b, snapshot, save)
+
+    def sn_snapshot(self, dev, power_iter=True, save=True):
+        """one power iteration of the four spectrally normalised blocks (u, v updated in place as the reference's training-mode forward does) and this
+        call's snapshots (u, v, [sigma, 1/sigma]) -- all a forward / backward pass of this call reads afterwards. Depends on the weights only, so the
+        generator step takes both of its calls' snapshots up front, in order, and runs the second call's chain beside the generator."""
         if not self.head_packed:
             self.repack()
-        dt, dev = self.dt, img_a.device
-        N, C, S, _ = img_a.shape
-        ctx = _Ctx()
-        ctx.N, ctx.S = N, S
-        x8 = ops.pack_nhwc8(dt, img_a, img_b)
-        ctx.ins, ctx.raw, ctx.sn = [], [], []
-        cur = x8
         # spectral norm of all four blocks in one batched power iteration; per-call snapshots of u, v, sigma for the backward
         Ws = [self.params[f"model.{i}.parametrizations.weight.original"] for i, _, _ in D_BLOCKS]
         us = [self.buffers[f"model.{i}.parametrizations.weight.0._u"] for i, _, _ in D_BLOCKS]
@@ -370,6 +382,18 @@ class DiscriminatorCore:
         sig = [snap[offs[2 * L + k]:offs[2 * L + k] + 2] for k in range(L)]
         self._sn_ws = ops.spectral_norm_step_batched(Ws, us, vs, sig, power_iter=power_iter, u_snaps=usn if save else None,
                                                      v_snaps=vsn if save else None, ws=getattr(self, "_sn_ws", None))
+        return usn, vsn, sig
+
+    def chain(self, img_a, img_b, snapshot, save=True):
+        """the convolution chain of one call, given its sn_snapshot()"""
+        usn, vsn, sig = snapshot
+        dt, dev = self.dt, img_a.device
+        N, C, S, _ = img_a.shape
+        ctx = _Ctx()
+        ctx.N, ctx.S = N, S
+        x8 = ops.pack_nhwc8(dt, img_a, img_b)
+        ctx.ins, ctx.raw, ctx.sn = [], [], []
+        cur = x8
         for bi, (i, cin, cout) in enumerate(D_BLOCKS):
             sigma2 = sig[bi]
             h = cur.H
@@ -388,6 +412,23 @@ class DiscriminatorCore:
         ops.patchgan_head_fwd(dt, cur, self.params["model.13.weight"], View(logits.t, 1, 0))
         ctx.p4 = cur
         return View(logits.t, 1, 0), (ctx if save else None)
+
+    def forward_pair(self, a1, b1, a2, b2, power_iter=True, save=True):
+        """forward(a1, b1) then forward(a2, b2), same results as the two calls in that order (the second power iteration follows the first). With the
+        side stream on, the second call's convolution chain runs beside the first's: two independent chains of MFMA-bound GEMMs and HBM-bound
+        blur-pools that fill each other's gaps."""
+        if not _SIDE["on"] or os.environ.get("TFC_NO_FWD_PAIR", "0") not in ("", "0"):      # (A/B knob)
+            return self.forward(a1, b1, power_iter, save), self.forward(a2, b2, power_iter, save)
+        dev = a1.device
+        if not self.head_packed:
+            self.repack()
+        box = {}
+
+        def second():
+            box["r"] = _on_side(dev, lambda: self.forward(a2, b2, power_iter, save))
+        first = self.forward(a1, b1, power_iter, save, after_sn=second)
+        _join_side(dev)
+        return first, box["r"]
 
     def backward(self, ctx, g_logits, grads=None, need_input_grad=True, accumulate=False, hook=None, ws=None):
         try:
