@@ -94,10 +94,11 @@ class TrainStep:
             self._pversions = pv
         ops.arena_begin(self.dev)                                 # one fill for all the small zero-initialised buffers of this step
         # ---------------- generator step ----------------
-        def pixel_losses():
+        def pixel_losses():                                       # everything that needs only the generated image (beside the discriminator chain)
             lt, gt = ops.patch16_triplet(fake, real_B, neg_idx, want_grad=True, gscale=self.lambda_trip)
             lf = patch_fft_loss(fake, real_B) if self.fft_mode == "patch" else global_fft_loss(fake, real_B)
-            return lt, gt, lf
+            ex = extra_loss_G(fake, real_B) if extra_loss_G is not None else None     # optional pluggable term (LPIPS, P16:598): (loss, dfake), already weighted
+            return lt, gt, lf, ex
         if nets.side_stream_on() and os.environ.get("TFC_NO_GSTEP_OVERLAP", "0") in ("", "0"):
             # Two-stream form of the same program (nets.py: side stream). Both power iterations of this step's two discriminator calls come first, in
             # call order (they read the weights only); the chain of the SECOND call (real pair, no gradient) then runs beside the generator forward,
@@ -105,23 +106,23 @@ class TrainStep:
             snap_f = self.D.sn_snapshot(self.dev, True, True)
             snap_r = self.D.sn_snapshot(self.dev, True, False)
             pr = nets.on_side(self.dev, lambda: self.D.chain(real_B, real_A, snap_r, save=False), snap_r[2][0])[0]
+            pr_ready = nets.side_mark(self.dev)
             fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
-            side_losses = nets.on_side(self.dev, pixel_losses)
+            loss_trip, g_trip, (loss_fft, loss_amp, loss_pha), extra_pair = nets.on_side(self.dev, pixel_losses)
             pf, dctx_f = self.D.chain(fake, real_A, snap_f, save=True)
-            nets.join_side(self.dev)
-            loss_trip, g_trip, (loss_fft, loss_amp, loss_pha) = side_losses
+            nets.wait_mark(self.dev, pr_ready)                    # the logits of the real pair; the pixel losses (LPIPS: 6 ms) run on, D.backward below joins
         else:
             fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
             pf, dctx_f = self.D.forward(fake, real_A, power_iter=True, save=True)
             pr, _ = self.D.forward(real_B, real_A, power_iter=True, save=False)
-            loss_trip, g_trip, (loss_fft, loss_amp, loss_pha) = pixel_losses()
+            loss_trip, g_trip, (loss_fft, loss_amp, loss_pha), extra_pair = pixel_losses()
         g_pf = self._gl(pf)
         loss_gan = ops.bce_relativistic(dt, pf, pr, 0, 0.9, da=ops.View(g_pf.t, 1, 0), gscale=self.lambda_gan)
         g_fake = self.D.backward(dctx_f, g_pf, grads=None, need_input_grad=True)
         ops.axpby(g_fake, g_fake, g_trip, 1.0, 1.0)
         extra = None
-        if extra_loss_G is not None:                              # optional pluggable term (LPIPS, P16:598): returns (loss, dfake), already weighted
-            extra, g_extra = extra_loss_G(fake, real_B)
+        if extra_pair is not None:
+            extra, g_extra = extra_pair
             ops.axpby(g_fake, g_fake, g_extra, 1.0, 1.0)
         self.G.backward(gctx, g_fake, self.gflat.grad_views, hook=self.g_reduce.ready)
         def g_update():

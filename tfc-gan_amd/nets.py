@@ -76,6 +76,21 @@ def side_stream_on():
 
 on_side, join_side = _on_side, _join_side
 
+
+def side_mark(dev):
+    """an event behind everything queued on the side stream so far (None when the side stream is not in use); wait_mark() makes the caller's stream wait
+    for it -- a partial join: what was queued on the side stream AFTER the mark keeps running beside the caller"""
+    if not _side_active():
+        return None
+    ev = torch.cuda.Event()
+    ev.record(_side_stream(dev))
+    return ev
+
+
+def wait_mark(dev, ev):
+    if ev is not None:
+        torch.cuda.current_stream(dev).wait_event(ev)
+
 # (name, Cin, Cout, normalize, dropout)  -- reference :140-145
 G_DOWN = [("down1", 3, 64, False, 0.0), ("down2", 64, 128, True, 0.0), ("down3", 128, 256, True, 0.5),
           ("down4", 256, 512, True, 0.5), ("down5", 512, 512, False, 0.0), ("down6", 512, 512, True, 0.0)]
