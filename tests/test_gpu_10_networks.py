@@ -447,9 +447,17 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
     FWD, BWD = 5e-4, 5e-3           # observed: forward <= 9.4e-5, backward <= 3.0e-3 (the dgrads that round an accumulated skip gradient)
     worst = [0.0, 0.0]
 
+    # The two smallest layers (down6: 7 x 7 output pixels, up1: 4 x 4 input) at batch 1: each weight-gradient entry sums <= 49 products, so ONE bf16
+    # rounding tie between the engine's stored gradient and the oracle's moves the whole rel-L2. Sampled over 45 processes (both stream modes, the
+    # inputs differ in the last bit from run to run through the InstanceNorm float atomics upstream): median 5e-6, 4.7e-4 / 2.8e-3 / 5.8e-3 / 8.0e-3
+    # in the tail. Their weight gradients get 2e-2 (still an order below a wrong tap or a dropped pixel); every other comparison keeps 5e-3.
+    TINY = {"down6 wgrad": 2e-2, "up1 wgrad": 2e-2}
+
     def check(tag, got, want, tol, slot):
         r = _rel(got, want)
-        worst[slot] = max(worst[slot], r)
+        tol = TINY.get(tag, tol)
+        if tag not in TINY:
+            worst[slot] = max(worst[slot], r)
         print(f"  {tag:34s} rel-L2 {r:.3e}")
         assert r <= tol, (tag, r)
 
