@@ -15,6 +15,11 @@
  *   - weights / gradients / statistics / losses are fp32 in the torch layouts of the reference's state_dict;
  *   - return value 0 = success, otherwise a negative code; tfc_last_error() gives the thread-local message.
  *     No entry point allocates, frees or synchronises (all are hipGraph-capturable).
+ *   - DETERMINISM: no entry point of the training path adds floats with atomics. Sums that cross workgroups (InstanceNorm statistics, their
+ *     backward reductions, bias gradients, spectral-norm products, split-K weight gradients) leave every workgroup as a partial in a
+ *     FIXED slot of a scratch buffer and are added in a fixed order behind the kernel: the same inputs give the same bits on every run.
+ *     Entry points that reduce therefore take `part_ws`: tfc_part_ws_floats() floats (32 MiB) of device scratch that only launches
+ *     of ONE stream use at a time (the Python side keeps one per (device, stream)); contents are undefined between calls.
  */
 #ifndef TFC_GAN_H
 #define TFC_GAN_H
@@ -37,7 +42,7 @@ extern "C" {
 
 /* epilogue flags of tfc_conv_fwd / tfc_conv_dgrad */
 #define TFC_EP_BIAS 1       /* + bias[Cout]                                                                                   */
-#define TFC_EP_STATS 2      /* stats[N][Cout][2] += (sum, sum of squares) of the result: nn.InstanceNorm2d statistics, P16:107 */
+#define TFC_EP_STATS 2      /* stats[N][Cout][2] += (sum, sum of squares) of the result: nn.InstanceNorm2d statistics, P16:107 (needs part_ws) */
 #define TFC_EP_ACCUM 4      /* result += existing output (skip-connection gradient accumulation, torch.cat backward P16:133)  */
 #define TFC_EP_TANH_NCHW 8  /* nn.Tanh (P16:157) and store fp32 NCHW to `out_nchw`                                            */
 #define TFC_EP_LEAKY 16     /* nn.LeakyReLU(0.2) of Discriminator1 (P16:190) applied to the result before it is stored          */
@@ -45,6 +50,7 @@ extern "C" {
 
 const char* tfc_last_error(void);
 int tfc_abi_version(void);
+size_t tfc_part_ws_floats(void);   /* size (floats) of the per-stream partial-sum scratch `part_ws` */
 
 /* ---- weights ------------------------------------------------------------------------------------------------- */
 /* pass: 0 = forward operand stream, 1 = dgrad operand stream.  w is the torch-layout fp32 weight
@@ -64,7 +70,8 @@ int tfc_conv_pack_planned(void* stream, int dt, const void* plan_dev, int njobs,
  * oscale: nullable DEVICE scalar multiplying the accumulator before the bias -- 1/sigma of spectral_norm (P16:188), so the
  * discriminator's operand streams are packed once per weight update and not once per forward. */
 int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
-                 const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags);
+                 const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags,
+                 float* part_ws /* nullable unless TFC_EP_STATS */);
 /* ---- PatchGAN head forward, P16:201-202: ZeroPad2d((1,0,1,0)) + Conv2d(C,1,k4,p1,no bias) as a wave-per-pixel dot product
  * (w: torch-layout fp32 [1][C][4][4], y: [N][H][W][y_pitch] channel 0). Same result as tfc_conv_fwd(TFC_OP_PADCONV, Cout=1). */
 int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* w,
@@ -106,31 +113,37 @@ int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x_pitch, con
  *            mode 1: rstats[N][C][2] += (sum g', sum g' * xhat)          (InstanceNorm backward, reduction phase)
  *            mode 2: dx = rstd * (g' - mean g' - xhat * mean(g' xhat))   (apply phase)
  *            g' = Blur^T(dropmask * dy) * Act'(xhat) ; x == NULL => Act' = 1
+ *   part_ws: needed whenever stats_out (forward) or a reduction into rstats (backward mode 1, mode 0 with rstats) is requested
  */
 int tfc_act_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* stats, int norm,
-                float slope, int pool, float drop_p, uint32_t seed, void* y, int y_pitch, float* stats_out);
+                float slope, int pool, float drop_p, uint32_t seed, void* y, int y_pitch, float* stats_out, float* part_ws);
 int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int dy_pitch, const void* x, int x_pitch, int N, int H, int W, int C,
-                const float* stats, int norm, float slope, int pool, float drop_p, uint32_t seed, float* rstats, void* dx, int dx_pitch);
+                const float* stats, int norm, float slope, int pool, float drop_p, uint32_t seed, float* rstats, void* dx, int dx_pitch, float* part_ws);
 int tfc_dropout_mask(void* stream, uint8_t* keep, long long n, float drop_p, uint32_t seed);   /* test hook: the mask itself */
 
 /* ---- layout plumbing at the NCHW fp32 module boundary -------------------------------------------------------------- */
 int tfc_pack_nhwc8(void* stream, int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int H, int W);   /* torch.cat((a,b),1), P16:207 */
 int tfc_unpack_nchw(void* stream, int dt, const void* in, int pitch, int c0, int C, float* out, int N, int H, int W, float alpha, float beta);
-int tfc_tanh_bwd_pack(void* stream, int dt, const float* g, const float* y, void* dyraw, float* dbias, int N, int C, int H, int W);
-int tfc_colsum(void* stream, int dt, const void* x, long long rows, int pitch, int C, float* out);   /* bias gradient (out += ) */
+/* nn.Tanh backward of the generator head (P16:157) + NHWC8 packing: dyraw = g * (1 - y^2); dbias (nullable, needs part_ws): float[C] += column sums */
+int tfc_tanh_bwd_pack(void* stream, int dt, const float* g, const float* y, void* dyraw, float* dbias, int N, int C, int H, int W, float* part_ws);
+/* bias gradient: out[C] += column sums of x [rows][pitch]; part_ws (nullable): lets many rows be split over workgroups */
+int tfc_colsum(void* stream, int dt, const void* x, long long rows, int pitch, int C, float* out, float* part_ws);
 int tfc_cast(void* stream, int dt, int to_f32, const void* x, void* y, long long n);
 int tfc_axpby(void* stream, float* out, const float* x, const float* y, long long n, float a, float b);
 
 /* ---- spectral norm: torch.nn.utils.parametrizations.spectral_norm, P16:188 ---------------------------------------- */
-/* W: [R][K] fp32; u[R], v[K] updated in place when power_iter != 0; sigma2 = {sigma, 1/sigma}; ws: (R+K) floats */
+/* W: [R][K] fp32; u[R], v[K] updated in place when power_iter != 0 (u <- norm(W v), v <- norm(W^T u)); sigma2 = {sigma, 1/sigma} with
+ * sigma = u . (W v), evaluated as (W^T u) . v after a power iteration (the same number up to fp32 round-off, one pass over W less);
+ * ws: tfc_spectral_norm_batched_ws_floats(1, &R, &K) floats */
 int tfc_spectral_norm_step(void* stream, const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter);
 /* the same for up to 4 layers in 3 launches (host arrays of device pointers / sizes); u_snap / v_snap (nullable arrays of
- * nullable pointers) receive copies of the updated u, v for the backward of THIS forward call; ws: ..._ws_floats() floats */
+ * nullable pointers) receive copies of the updated u, v for the backward of THIS forward call; ws: ..._ws_floats() floats
+ * (W^T u is formed from per-row-block partials that are added in a fixed order: no atomics) */
 size_t tfc_spectral_norm_batched_ws_floats(int nlayers, const int* R_host, const int* K_host);
 int tfc_spectral_norm_step_batched(void* stream, int nlayers, const float* const* W_host, float* const* u_host, float* const* v_host,
                                    float* const* sigma2_host, float* const* u_snap_host, float* const* v_snap_host,
                                    const int* R_host, const int* K_host, float* ws, int power_iter);
-/* gW_orig (=/+=) (G - <G, W/sigma> u v^T) / sigma ; ws: 1 float */
+/* gW_orig (=/+=) (G - <G, W/sigma> u v^T) / sigma ; ws: 256 floats, 8-byte aligned (per-workgroup partials of <G, W>, added in a fixed order) */
 int tfc_spectral_norm_bwd(void* stream, const float* G, const float* W, const float* u, const float* v, const float* sigma2,
                           float* ws, float* gout, int R, int K, int accumulate);
 
@@ -176,9 +189,11 @@ int tfc_adam_step(void* stream, float* p, const float* g, float* m, float* v, lo
 /* Net.forward, STN:228-229: F.affine_grid(theta, size, align_corners=True) + F.grid_sample(src, grid, mode='bicubic', padding_mode='border',
  * align_corners=True), fused (the grid is never stored). src / out: fp32 NCHW [N][C][H][W]; theta: [N][2][3] (identity already added, STN:208-211). */
 int tfc_affine_warp_fwd(void* stream, const float* src, const float* theta, float* out, int N, int C, int H, int W);
-/* backward: dtheta[N][6] = d loss / d theta (the trainable path: theta comes from the localiser); dsrc (nullable) = d loss / d src. Both are
- * overwritten (zeroed inside). gout: d loss / d out. */
-int tfc_affine_warp_bwd(void* stream, const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C, int H, int W);
+/* backward: dtheta[N][6] = d loss / d theta (the trainable path: theta comes from the localiser; per-workgroup partials in part_ws, added in a
+ * fixed order); dsrc (nullable) = d loss / d src (a scatter: float atomics, the one order-dependent output of the library -- the STN21 step
+ * never asks for it). Both are overwritten (zeroed inside). gout: d loss / d out. */
+int tfc_affine_warp_bwd(void* stream, const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C, int H, int W,
+                        float* part_ws);
 /* morph_triplet, STN:444-449: kornia.morphology.gradient(x, [[0,1,0],[1,1,1],[0,1,0]]) = dilation - erosion with geodesic borders (neighbours
  * outside the image never win). x / out: fp32, `planes` images of H x W; arg (nullable): per pixel arg-max | arg-min << 4 for the backward. */
 int tfc_morph_grad_fwd(void* stream, const float* x, float* out, uint8_t* arg, long long planes, int H, int W);
@@ -193,10 +208,10 @@ int tfc_row_triplet_grad(void* stream, const float* anchor, const float* positiv
  * (and bias) gradient, it is never written: = tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad(TFC_OP_CONV) in one kernel, same bits.
  * x: NHWC8 input image [N][H][W][8]; y: the stored conv output [N][H-1][W-1] (its sign is all that is read: pre- or post-activation);
  * dy_pooled: gradient of the pooled output [N][Ho][Wo], Ho = (H-2)/2+1; dw: torch-layout gradient [Cout][Cin][4][4] (=/+=);
- * bias_sums (nullable): float[N][Cout] += per-image sums of the conv-output gradient; ws: tfc_conv_wgrad_ws_bytes() of scratch (zeroed once). ---- */
+ * bias_sums (nullable, needs part_ws): float[N][Cout] += per-image sums of the conv-output gradient; ws: tfc_conv_wgrad_ws_bytes() of scratch (zeroed once). ---- */
 int tfc_first_block_bwd_supported(int dt, int Cin, int Cout);
 int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, int x_pitch, const void* y, int y_pitch, const void* dy_pooled, int dyp_pitch, int N, int H,
-                              int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums);
+                              int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums, float* part_ws);
 
 /* ---- input pipeline: ImageDataset.__getitem__, TFC-GAN-FFT/datasets_temp.py:38-123 --------------------------
  * A decoded file is one RGB uint8 image [H][W][3] with the visible image A in columns [0, xsplit) and the thermal image B in [xsplit, W),

@@ -19,7 +19,7 @@ for H, Cin, Cout in shapes:
     stamps = torch.zeros(1 << 20, dtype=torch.int64, device=DEV)
     for _ in range(3):
         ops.check(lib.tfc_conv_fwd(ops.stream_ptr(), dt, ops.OP_CONV, x.ptr, x.pitch, N, H, H, Cin, Cout, ops._p(pk), y.ptr, y.pitch, None, None,
-                                   ops._p(stamps), None, 0), "conv")
+                                   ops._p(stamps), None, 0, None), "conv")
     torch.cuda.synchronize()
     s = stamps.cpu().numpy().reshape(-1, 16)
     s = s[s[:, 0] != 0].astype(np.int64)

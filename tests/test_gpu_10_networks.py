@@ -238,33 +238,40 @@ def test_full_size_properties_batch32():
 
 
 @pytest.mark.parametrize("cdt", [torch.bfloat16, torch.float32])
-def test_wgrad_side_stream_same_gradients(cdt):
-    """nets.py runs the weight gradients on a second stream beside the input-gradient chain (product default). One step with and without it, from the
-    same weights and inputs, must produce the same parameter gradients up to the run-to-run spread of the float atomics upstream (InstanceNorm sums,
-    loss sums): a missing dependency or a temporary handed back to the allocator too early would show as a gross error."""
+def test_step_is_bit_deterministic_on_one_and_two_streams(cdt):
+    """no float atomics on the training path -- sums that cross workgroups (InstanceNorm statistics and their backward reductions,
+    bias gradients, spectral-norm products, split-K weight gradients) are added in a fixed order. Two steps from the same weights and inputs therefore
+    give the SAME BITS: both flat gradient buffers, the post-Adam weights, the spectral-norm vectors and the logged losses, run to run on two streams
+    (the product default) and against the one-stream schedule (nets.py: the side stream changes WHEN kernels run, never what they compute).
+    Round 2 could only assert a cosine here (bf16 generator gradients agreed run to run to cos 0.991)."""
     T.set_compute_dtype(cdt)
-    grads = []
+    runs = []
     prev = T.set_wgrad_stream(True)
     try:
-        for on in (True, False):
+        for on in (True, True, False):
             T.set_wgrad_stream(on)
             G = O.init_weights_portable(T.GeneratorUNet((3, 256, 256)), seed=71).to(DEV)
             D = O.init_weights_portable(T.Discriminator1((3, 256, 256)), seed=72).to(DEV)
             A, B = O.synthetic_pairs(2, seed=73)
             A, B = A.to(DEV), B.to(DEV)
             ts = T.TrainStep(G, D, compute_dtype=cdt)
-            ts.step(A, B)
+            out = ts.step(A, B)
+            out2 = ts.step(A, B)                                  # a second step: Adam state, re-packed operand streams, evolved u / v
             torch.cuda.synchronize()
-            grads.append((ts.gflat.grad.clone(), ts.dflat.grad.clone()))
+            runs.append({"g_grad": ts.gflat.grad.clone(), "d_grad": ts.dflat.grad.clone(), "g_w": ts.gflat.data.clone(), "d_w": ts.dflat.data.clone(),
+                         "fake": out2["fake_B"].clone(), "sn": torch.cat([b.flatten() for b in ts.dbufs.values()]).clone(),
+                         "losses": torch.stack([out2[k].reshape(()).float() for k in sorted(out2) if k != "fake_B"]).clone(),
+                         "views": {k: v.clone() for k, v in list(ts.gflat.grad_views.items()) + list(ts.dflat.grad_views.items())}})
     finally:
         T.set_wgrad_stream(prev)
         T.set_compute_dtype(torch.float32)
-    # measured spread between two runs of the SAME setting (scripts/side_stream_check.py: float atomics upstream): fp32 cos 0.999996 / 1.000000 (G / D),
-    # bf16 0.991 / 0.999995 -- the on-vs-off figures are the same numbers
-    for (g1, g0), lim in zip(zip(*grads), ((0.9999, 0.97), (0.99999, 0.9995))):
-        assert torch.isfinite(g1).all() and g0.abs().max().item() > 0
-        cos = F.cosine_similarity(g1.double(), g0.double(), dim=0).item()
-        assert cos > (lim[0] if cdt == torch.float32 else lim[1]), cos
+    ref = runs[0]
+    assert torch.isfinite(ref["g_grad"]).all() and ref["g_grad"].abs().max().item() > 0 and ref["d_grad"].abs().max().item() > 0
+    for what, other in (("two streams, run to run", runs[1]), ("two streams vs one stream", runs[2])):
+        bad = [k for k in ref["views"] if not torch.equal(ref["views"][k], other["views"][k])]
+        assert not bad, (what, "parameter gradients differ", bad)
+        for k in ("g_grad", "d_grad", "g_w", "d_w", "fake", "sn", "losses"):
+            assert torch.equal(ref[k], other[k]), (what, k, (ref[k].double() - other[k].double()).abs().max().item())
 
 
 def test_module_forward_sees_weights_updated_by_trainstep():
@@ -420,14 +427,43 @@ def _rel(got, want):
     return ((got.double() - want.double()).norm() / want.double().norm().clamp_min(1e-30)).item()
 
 
+class _EngineStatsNorm(torch.autograd.Function):
+    """nn.InstanceNorm2d (P16:107, :124) evaluated with the ENGINE's statistics: x_hat = (x - mean) * rstd with (mean, rstd) derived from the engine's
+    (sum, sum of squares) exactly as its kernels derive them (fp32: m = s1 * (1 / HW), var = max(s2 / HW - m^2, 0), rstd = rsqrt(var + eps)); backward =
+    the InstanceNorm backward with those same constants. Teacher-forcing the statistics takes the one knife edge out of the per-layer comparison:
+    sign(x - mean) -- the LeakyReLU / ReLU mask -- is then decided by identical fp32 numbers on both sides (the 5e-3..8e-3 tail of the
+    7 x 7 layers was ONE mask flip, 0.8 |g| / sqrt(25088), caused by a last-bit difference of the mean)."""
+
+    @staticmethod
+    def forward(ctx, x, stats, eps):
+        hw = x.shape[2] * x.shape[3]
+        inv = torch.tensor(1.0 / hw, dtype=torch.float32)
+        m = (stats[..., 0] * inv)[:, :, None, None]
+        var = (stats[..., 1] * inv)[:, :, None, None] - m * m
+        r = torch.rsqrt(var.clamp_min(0.0) + eps)
+        xh = (x - m) * r
+        ctx.save_for_backward(xh, r)
+        return xh
+
+    @staticmethod
+    def backward(ctx, g):
+        xh, r = ctx.saved_tensors
+        mg = g.mean(dim=(2, 3), keepdim=True)
+        mgx = (g * xh).mean(dim=(2, 3), keepdim=True)
+        return r * (g - mg - xh * mgx), None, None
+
+
 def test_bf16_layers_teacher_forced_vs_storage_oracle():
     """bf16 is the benchmarked dtype, and end to end a bf16 network is chaotic: a 1-ulp tie broken differently (different fp32 summation order)
     changes 1 % of the next layer's roundings, 18 % after two more layers, everything after six -- so NO independent implementation, however
     faithful, agrees end to end to better than ~1e-2 (scripts/debug_bf16_layers.py prints the growth). What CAN be tight is every layer on its
     own: each layer of the bf16 engine is fed to the oracle's bf16-STORAGE model of that layer (round to bf16 where the engine stores bf16, fp32 in
-    between: oracle._RoundBoth / _RoundFwd / _RoundBwd) with the ENGINE's stored input, forward and backward: outputs, input gradients and weight
-    gradients of all 12 generator layers must agree to 1-ulp ties (rel-L2 <= 5e-4 forward, <= 5e-3 backward). A 10 % error in any bf16-only
-    kernel (first-layer conv, pooled activation, up-conv head, transposed-conv phases, fused wgrads) fails here by an order of magnitude."""
+    between: oracle._RoundBoth / _RoundFwd / _RoundBwd) with the ENGINE's stored input AND the engine's InstanceNorm statistics (_EngineStatsNorm: the
+    activation mask is then decided by identical numbers on both sides), forward and backward: outputs, input gradients and weight gradients of all
+    12 generator layers must agree to 1-ulp ties (rel-L2 <= 5e-4 forward, <= 5e-3 backward, NO per-layer exceptions). A 10 % error in any bf16-only
+    kernel (first-layer conv, pooled activation, up-conv head, transposed-conv phases, fused wgrads) fails here by an order of magnitude. Every
+    weight-gradient line also reports how many elements of the engine's stored conv-output gradient differ from the oracle's, and by how much, so a
+    miss is explained by the one run that shows it."""
     T.set_compute_dtype(torch.bfloat16)
     torch.set_num_threads(16)
     Gc = O.init_weights_portable(O.GeneratorUNet((3, 256, 256)), seed=61).eval()
@@ -447,19 +483,20 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
     FWD, BWD = 5e-4, 5e-3           # observed: forward <= 9.4e-5, backward <= 3.0e-3 (the dgrads that round an accumulated skip gradient)
     worst = [0.0, 0.0]
 
-    # The two smallest layers (down6: 7 x 7 output pixels, up1: 4 x 4 input) at batch 1: each weight-gradient entry sums <= 49 products, so ONE bf16
-    # rounding tie between the engine's stored gradient and the oracle's moves the whole rel-L2. Sampled over 45 processes (both stream modes, the
-    # inputs differ in the last bit from run to run through the InstanceNorm float atomics upstream): median 5e-6, 4.7e-4 / 2.8e-3 / 5.8e-3 / 8.0e-3
-    # in the tail. Their weight gradients get 2e-2 (still an order below a wrong tap or a dropped pixel); every other comparison keeps 5e-3.
-    TINY = {"down6 wgrad": 2e-2, "up1 wgrad": 2e-2}
-
     def check(tag, got, want, tol, slot):
         r = _rel(got, want)
-        tol = TINY.get(tag, tol)
-        if tag not in TINY:
-            worst[slot] = max(worst[slot], r)
+        worst[slot] = max(worst[slot], r)
         print(f"  {tag:34s} rel-L2 {r:.3e}")
         assert r <= tol, (tag, r)
+
+    def draw_report(tag, got, want):
+        """engine's stored conv-output gradient vs the oracle's (bf16-rounded): count / size of the differences"""
+        d = (got.double() - want.double()).abs()
+        scale = want.double().abs().max().item() + 1e-30
+        n_diff = int((d > 0).sum())
+        n_big = int((d > 0.02 * want.double().abs().clamp_min(1e-3 * scale)).sum())      # more than a few bf16 ulps: a flipped mask, not a tie
+        print(f"  {tag:34s} d_raw: {n_diff} of {d.numel()} elements differ, {n_big} by more than 2 %, max |diff| / max |want| = {d.max().item() / scale:.2e}")
+        return n_big
 
     # ---- down path: layer i maps its stored input to raw (conv) and to the pooled output; backward from the engine's own g_out ----
     skip_of = {4: "up1", 3: "up2", 2: "up3", 1: "up4", 0: "up5"}
@@ -472,7 +509,7 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
         check(f"{name} conv fwd", _nchw(ctx.raw[i]), z.detach(), FWD, 0)
         raw_e = _nchw(ctx.raw[i])
         zt = z + (raw_e - z).detach()                               # teacher forcing: continue from the ENGINE's stored conv output
-        zz = F.instance_norm(zt, eps=1e-5) if norm else zt
+        zz = _EngineStatsNorm.apply(zt, ctx.stats[i].float().cpu(), 1e-5) if norm else zt
         y = rb(O._blur(F.leaky_relu(zz, 0.2), 2))
         if i < 5:
             cat = ctx.cat[skip_of[i]]
@@ -482,9 +519,10 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
         check(f"{name} norm/act/pool fwd", y_e, y.detach(), FWD, 0)
         g_out = _nchw(dbg[f"{name}.g_out"])
         ins = [w] + ([x] if i > 0 else [])
-        gr = torch.autograd.grad(y, ins, g_out)
+        gr = torch.autograd.grad(y, ins + [zt], g_out)
+        if f"{name}.d_raw" in dbg:
+            assert draw_report(f"{name}", _nchw(dbg[f"{name}.d_raw"]), O._bf(gr[-1])) == 0, name
         check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gr[0], BWD, 1)
-        dz = torch.autograd.grad(zt, z, torch.ones_like(z), allow_unused=True) if False else None
         if i > 0:
             # the engine ACCUMULATES this input gradient onto the up path's part of the skip window: g_out(prev) = bf16(g_in(up)[skip] + dgrad)
             up = skip_of[i - 1]
@@ -506,12 +544,13 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
         zb = rb(O._blur(zT, 1))
         check(f"{name} convT+blur fwd", _nchw(ctx.blur[j]), zb.detach(), FWD, 0)
         zt = zb + (_nchw(ctx.blur[j]) - zb).detach()
-        y = rb(F.relu(F.instance_norm(zt, eps=1e-5)))
+        y = rb(F.relu(_EngineStatsNorm.apply(zt, ctx.bstats[j].float().cpu(), 1e-5)))
         cat = ctx.cat[name]
         y_e = cat.t[..., :cout].float().cpu().permute(0, 3, 1, 2).contiguous()
         check(f"{name} norm/relu fwd", y_e, y.detach(), FWD, 0)
         g_cat = _nchw(dbg[f"{name}.g_out"])
-        gw, gx = torch.autograd.grad(y, [w, x], g_cat[:, :cout])
+        gw, gx, gzb = torch.autograd.grad(y, [w, x, zt], g_cat[:, :cout])
+        assert draw_report(f"{name} (d_blur)", _nchw(dbg[f"{name}.d_blur"]), O._bf(gzb)) == 0, name
         # (until the blur kernels took the InstanceNorm sums from the STORED bf16 values, up1 -- 8 x 8 planes -- sat at 0.5..1.2e-2 here)
         check(f"{name} wgrad", grads[f"{name}.model.0.weight"].cpu(), gw, BWD, 1)
         check(f"{name} dgrad", _nchw(dbg[f"{name}.g_in"]), O._bf(gx), BWD, 1)

@@ -25,12 +25,12 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tfc_abi_version() == 1
+    assert lib.tfc_abi_version() == 2
 
 
 def test_errors_are_loud():
     lib = _lib.load()
-    rc = lib.tfc_conv_fwd(None, 7, 0, None, 0, 1, 8, 8, 8, 8, None, None, 0, None, None, None, None, 0)
+    rc = lib.tfc_conv_fwd(None, 7, 0, None, 0, 1, 8, 8, 8, 8, None, None, 0, None, None, None, None, 0, None)
     assert rc != 0 and b"dtype" in lib.tfc_last_error()
     with pytest.raises(T.TfcError):
         _lib.check(rc, "tfc_conv_fwd")

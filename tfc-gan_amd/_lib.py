@@ -55,13 +55,14 @@ _vp, _i, _f, _ll, _u32, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_longlong, 
 PROTOTYPES = {
     "tfc_last_error": (_c.c_char_p, []),
     "tfc_abi_version": (_i, []),
+    "tfc_part_ws_floats": (_sz, []),
     "tfc_conv_packed_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "tfc_conv_pack": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i]),
     "tfc_pack_plan_bytes": (_sz, [_i]),
     "tfc_pack_plan_build": (_i, [_i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i), _c.POINTER(_i),
                                  _vp, _c.POINTER(_i)]),
     "tfc_conv_pack_planned": (_i, [_vp, _i, _vp, _i, _i]),
-    "tfc_conv_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    "tfc_conv_fwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "tfc_conv_dgrad_image": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "tfc_upconv_head_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tfc_upconv_head_dgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
@@ -69,13 +70,13 @@ PROTOTYPES = {
     "tfc_conv_dgrad": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i]),
     "tfc_conv_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "tfc_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
-    "tfc_act_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _i, _vp]),
-    "tfc_act_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _vp, _i]),
+    "tfc_act_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _i, _vp, _vp]),
+    "tfc_act_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _vp, _i, _vp]),
     "tfc_dropout_mask": (_i, [_vp, _vp, _ll, _f, _u32]),
     "tfc_pack_nhwc8": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i]),
     "tfc_unpack_nchw": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f]),
-    "tfc_tanh_bwd_pack": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
-    "tfc_colsum": (_i, [_vp, _i, _vp, _ll, _i, _i, _vp]),
+    "tfc_tanh_bwd_pack": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfc_colsum": (_i, [_vp, _i, _vp, _ll, _i, _i, _vp, _vp]),
     "tfc_cast": (_i, [_vp, _i, _i, _vp, _vp, _ll]),
     "tfc_axpby": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f]),
     "tfc_spectral_norm_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
@@ -91,12 +92,12 @@ PROTOTYPES = {
     "tfc_row_triplet": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
     "tfc_l1_sum": (_i, [_vp, _vp, _vp, _ll, _f, _vp, _i]),
     "tfc_affine_warp_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
-    "tfc_affine_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "tfc_affine_warp_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tfc_morph_grad_fwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
     "tfc_morph_grad_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
     "tfc_row_triplet_grad": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _vp, _vp]),
     "tfc_first_block_bwd_supported": (_i, [_i, _i, _i]),
-    "tfc_first_block_bwd_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
+    "tfc_first_block_bwd_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
     "tfc_resize_plan_bytes": (_sz, [_i, _i, _i]),
     "tfc_resize_plan_build": (_i, [_i, _i, _i, _vp]),
     "tfc_pair_resize_ws_bytes": (_sz, [_i, _i, _i]),

@@ -37,7 +37,7 @@ int tfc_nb32(int nout);
 int tfc_nb32_padded(int nout);
 size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
-hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st);
+hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st);
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st, TfcWgradFin* fin);
 hipError_t tfc_launch_dgrad_rows4(const void* dy, int dy_pitch, int N, int H, int W, const float* w, int Cin, const float* oscale, int NC, float* dx, hipStream_t st);
 hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int W, const float* w, const float* bias, int Cout, float* out, hipStream_t st);
@@ -45,13 +45,12 @@ bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW,
                                    int Cin, float* dwacc, void* slab, hipStream_t st, hipError_t* err, TfcWgradFin* fin);
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc, int accumulate, hipStream_t st);
 hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st);
-hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st);
-hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats, void* dx, int use_x, int dx_pitch, hipStream_t st);
-hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, hipStream_t st);
+hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, float* part_ws, hipStream_t st);
+hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats, void* dx, int use_x, int dx_pitch, float* part_ws, hipStream_t st);
+hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, float* part_ws, hipStream_t st);
 hipError_t tfc_launch_pack_nhwc8(int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int HW, hipStream_t st);
 hipError_t tfc_launch_unpack_nchw(int dt, const void* in, int pitch, int c0, int C, float* out, int N, int HW, float alpha, float beta, hipStream_t st);
-hipError_t tfc_launch_tanh_bwd_pack(int dt, const float* g, const float* y, void* out, float* dbias, int N, int C, int HW, hipStream_t st);
-hipError_t tfc_launch_sn_step(const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter, float eps, hipStream_t st);
+hipError_t tfc_launch_tanh_bwd_pack(int dt, const float* g, const float* y, void* out, float* dbias, float* part_ws, int N, int C, int HW, hipStream_t st);
 hipError_t tfc_launch_sn_bwd(const float* G, const float* W, const float* u, const float* v, const float* sigma2, float* dot_ws, float* gout, int R, int K, int accumulate, hipStream_t st);
 hipError_t tfc_launch_bce_rel(int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode, float* loss, void* da, void* db, float gscale, hipStream_t st);
 hipError_t tfc_launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale, hipStream_t st);
@@ -69,7 +68,7 @@ hipError_t tfc_launch_row_triplet(const float* a, const float* p, const float* n
                                   float* loss, hipStream_t st);
 hipError_t tfc_launch_head_fwd(int dt, const void* x, int x_pitch, const float* w, void* y, int y_pitch, int N, int H, int W, int C, hipStream_t st);
 hipError_t tfc_launch_affine_warp_fwd(const float* src, const float* theta, float* out, int N, int C, int H, int W, hipStream_t st);
-hipError_t tfc_launch_affine_warp_bwd(const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C, int H, int W, hipStream_t st);
+hipError_t tfc_launch_affine_warp_bwd(const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, float* part_ws, int N, int C, int H, int W, hipStream_t st);
 hipError_t tfc_launch_morph_grad_fwd(const float* x, float* out, unsigned char* arg, long long planes, int H, int W, hipStream_t st);
 hipError_t tfc_launch_morph_grad_bwd(const float* gout, const unsigned char* arg, float* dx, long long planes, int H, int W, hipStream_t st);
 hipError_t tfc_launch_row_triplet_grad(const float* a, const float* p, const float* ng, long long rows, int W, float margin, float eps, float gscale,
@@ -82,7 +81,7 @@ struct SnBatch {
   int R[4], K[4];
   int n;
 };
-hipError_t tfc_launch_sn_step_batched(const SnBatch& b, float* ws_t, size_t t_bytes, int power_iter, float eps, hipStream_t st);
+hipError_t tfc_launch_sn_step_batched(const SnBatch& b, int power_iter, float eps, hipStream_t st);
 
 // ---- error handling --------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -100,7 +99,8 @@ static int hipfail(hipError_t e, const char* where) { return fail(-100 - (int)e,
 #define REQUIRE(cond, ...) do { if (!(cond)) return fail(-1, __VA_ARGS__); } while (0)
 
 extern "C" const char* tfc_last_error(void) { return g_err.c_str(); }
-extern "C" int tfc_abi_version(void) { return 1; }
+extern "C" int tfc_abi_version(void) { return 2; }              // 2: deterministic reductions (part_ws arguments)
+extern "C" size_t tfc_part_ws_floats(void) { return (size_t)TFC_PART_WS_FLOATS; }
 
 static inline int pad8(int c) { return (c + 7) / 8 * 8; }
 static inline int es_of(int dt) { return dt == TFC_DT_BF16 ? 2 : 4; }
@@ -421,7 +421,8 @@ static double conv_flop(int op, int N, int H, int W, int Cin, int Cout) {
 }
 
 extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
-                            const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags) {
+                            const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags,
+                            float* part_ws) {
   if (int e = check_common(dt, op, N, H, W, Cin, Cout)) return e;
   if (int e = check_ptr16(x, "x")) return e;
   if (int e = check_ptr16(packed, "packed")) return e;
@@ -433,7 +434,7 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
     if (dt == TFC_DT_BF16 && Cout >= 8) REQUIRE(y_pitch % 8 == 0 && (((uintptr_t)y) & 15) == 0, "bf16 outputs are stored in 16-byte units: y must be 16-byte aligned with pitch %% 8 == 0");
   }
   if (flags & TFC_EP_BIAS) REQUIRE(bias != nullptr, "bias is null");
-  if (flags & TFC_EP_STATS) REQUIRE(stats != nullptr, "stats is null");
+  if (flags & TFC_EP_STATS) REQUIRE(stats != nullptr && part_ws != nullptr, "TFC_EP_STATS needs stats and part_ws");
   int nph = num_phases(op, 0);
   const bool fold = (op == TFC_OP_CONVT || op == TFC_OP_UPCONV);   // equal-shaped phases: fold all four into the grid of one launch
   if (fold) nph = 1;
@@ -443,7 +444,7 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
     if (int e = build_desc(op, 0, ph, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, nullptr)) return e;
     if (fold) { d.ph_n = 4; d.ph_d0 = (op == TFC_OP_CONVT) ? 1 : 0; d.ph_oo = 1; }   // phase 0 descriptor + per-phase shifts (convT: dy0 = py-1; both: OOY = py)
     if (int e = check_desc(d, dt)) return e;
-    CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
+    CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, part_ws, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
   }
   return 0;
 }
@@ -496,7 +497,7 @@ extern "C" int tfc_conv_dgrad(void* stream, int dt, int op, const void* dy, int 
   if (int e = build_desc(op, 1, 0, N, H, W, Cin, Cout, dy_pitch, dx_pitch, &d, nullptr)) return e;
   if (int e = check_desc(d, dt)) return e;
   ProfScope prof(0, conv_flop(op, N, H, W, Cin, Cout), (hipStream_t)stream, op, 1, N, H, W, Cin, Cout);
-  CHECK_HIP(tfc_launch_igemm(dt, d, dy, packed, dx, nullptr, nullptr, nullptr, oscale, flags, (hipStream_t)stream), "tfc_conv_dgrad");
+  CHECK_HIP(tfc_launch_igemm(dt, d, dy, packed, dx, nullptr, nullptr, nullptr, nullptr, oscale, flags, (hipStream_t)stream), "tfc_conv_dgrad");
   return 0;
 }
 
@@ -601,13 +602,15 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
 
 // ---- fused first-block backward --------------------------------------------------------------------------------------------------------
 hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
-                                      void* slab, float* dwacc, float* rstats, float slope, int Nn_real, int Cw_real, hipStream_t st);
+                                      void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real, hipStream_t st);
 extern "C" int tfc_first_block_bwd_supported(int dt, int Cin, int Cout) { return dt == TFC_DT_BF16 && Cin > 0 && Cin <= 8 && Cout == 64 ? 1 : 0; }
 extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, int x_pitch, const void* y, int y_pitch, const void* dy_pooled, int dyp_pitch,
-                                         int N, int H, int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums) {
+                                         int N, int H, int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums,
+                                         float* part_ws) {
   REQUIRE(tfc_first_block_bwd_supported(dt, Cin, Cout), "fused first-block backward: bf16, Cin <= 8, Cout == 64 (dt=%d Cin=%d Cout=%d)", dt, Cin, Cout);
   if (int e = check_common(dt, TFC_OP_CONV, N, H, W, Cin, Cout)) return e;
   REQUIRE(x && y && dy_pooled && ws && dw, "null argument");
+  REQUIRE(!bias_sums || part_ws, "bias_sums needs part_ws");
   REQUIRE(x_pitch == 8 && y_pitch >= 64 && y_pitch % 8 == 0 && dyp_pitch >= 64 && dyp_pitch % 8 == 0, "pitches: x %d (must be 8), y %d, dy %d", x_pitch, y_pitch, dyp_pitch);
   REQUIRE(H >= 4 && W >= 4, "reflect padding of the blur needs a 3 x 3 activation at least");
   if (int e = check_ptr16(x, "x")) return e;
@@ -623,7 +626,7 @@ extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, in
     // class 3, not 1: this launch also carries the (VALU-bound) transposed blur that used to be an elementwise pass of its own -- keeping it out of
     // the weight-gradient class keeps that class comparable across rounds
     ProfScope prof(3, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), st, TFC_OP_CONV, 2, N, H, W, Cin, Cout);
-    CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, slope, Cout, Cin, st),
+    CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, part_ws, slope, Cout, Cin, st),
               "tfc_first_block_bwd_wgrad");
   }
   {
@@ -656,18 +659,20 @@ static int fill_act(ActParams& p, int dt, int N, int H, int W, int C, int x_pitc
 }
 
 extern "C" int tfc_act_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* stats, int norm,
-                           float slope, int pool, float drop_p, uint32_t seed, void* y, int y_pitch, float* stats_out) {
+                           float slope, int pool, float drop_p, uint32_t seed, void* y, int y_pitch, float* stats_out, float* part_ws) {
   ActParams p;
   if (int e = fill_act(p, dt, N, H, W, C, x_pitch, y_pitch, norm, slope, pool, drop_p, seed)) return e;
   if (int e = check_ptr16(x, "x")) return e;
   if (int e = check_ptr16(y, "y")) return e;
   REQUIRE(!norm || stats, "stats is null");
-  CHECK_HIP(tfc_launch_act_fwd(dt, p, x, stats, y, stats_out, (hipStream_t)stream), "tfc_act_fwd");
+  REQUIRE(!stats_out || part_ws, "stats_out needs part_ws");
+  CHECK_HIP(tfc_launch_act_fwd(dt, p, x, stats, y, stats_out, part_ws, (hipStream_t)stream), "tfc_act_fwd");
   return 0;
 }
 
 extern "C" int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int dy_pitch, const void* x, int x_pitch, int N, int H, int W, int C,
-                           const float* stats, int norm, float slope, int pool, float drop_p, uint32_t seed, float* rstats, void* dx, int dx_pitch) {
+                           const float* stats, int norm, float slope, int pool, float drop_p, uint32_t seed, float* rstats, void* dx, int dx_pitch,
+                           float* part_ws) {
   ActParams p;
   if (int e = fill_act(p, dt, N, H, W, C, x ? x_pitch : C, dy_pitch, norm, slope, pool, drop_p, seed)) return e;
   REQUIRE(mode >= 0 && mode <= 2, "bad mode");
@@ -675,8 +680,9 @@ extern "C" int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int d
   REQUIRE(!norm || (stats && x), "norm needs stats and x");
   REQUIRE(mode == 0 || (norm && rstats), "modes 1/2 need norm and rstats");   // mode 0: rstats (nullable) = float[C] += column sums of dx
   REQUIRE(mode == 1 || dx, "dx is null");
+  REQUIRE(!(mode == 1 || (mode == 0 && rstats)) || part_ws, "a reduction into rstats needs part_ws");
   const void* xx = x ? x : dy;
-  CHECK_HIP(tfc_launch_act_bwd(dt, mode, p, dy, xx, stats, rstats, dx ? dx : (void*)dy, x ? 1 : 0, dx_pitch, (hipStream_t)stream), "tfc_act_bwd");
+  CHECK_HIP(tfc_launch_act_bwd(dt, mode, p, dy, xx, stats, rstats, dx ? dx : (void*)dy, x ? 1 : 0, dx_pitch, part_ws, (hipStream_t)stream), "tfc_act_bwd");
   return 0;
 }
 
@@ -696,15 +702,16 @@ extern "C" int tfc_unpack_nchw(void* stream, int dt, const void* in, int pitch, 
   CHECK_HIP(tfc_launch_unpack_nchw(dt, in, pitch, c0, C, out, N, H * W, alpha, beta, (hipStream_t)stream), "tfc_unpack_nchw");
   return 0;
 }
-extern "C" int tfc_tanh_bwd_pack(void* stream, int dt, const float* g, const float* y, void* dyraw, float* dbias, int N, int C, int H, int W) {
+extern "C" int tfc_tanh_bwd_pack(void* stream, int dt, const float* g, const float* y, void* dyraw, float* dbias, int N, int C, int H, int W, float* part_ws) {
   REQUIRE(g && y && dyraw && C > 0 && C <= 4, "bad args (C <= 4)");
-  CHECK_HIP(tfc_launch_tanh_bwd_pack(dt, g, y, dyraw, dbias, N, C, H * W, (hipStream_t)stream), "tfc_tanh_bwd_pack");
+  REQUIRE(!dbias || part_ws, "dbias needs part_ws");
+  CHECK_HIP(tfc_launch_tanh_bwd_pack(dt, g, y, dyraw, dbias, part_ws, N, C, H * W, (hipStream_t)stream), "tfc_tanh_bwd_pack");
   return 0;
 }
-extern "C" int tfc_colsum(void* stream, int dt, const void* x, long long rows, int pitch, int C, float* out) {
+extern "C" int tfc_colsum(void* stream, int dt, const void* x, long long rows, int pitch, int C, float* out, float* part_ws) {
   const int ue = 16 / es_of(dt);
-  REQUIRE(x && out && rows > 0 && C % ue == 0 && (256 % (C / ue)) == 0 && C / ue <= 256, "bad args");
-  CHECK_HIP(tfc_launch_colsum(dt, x, rows, pitch, C, out, (hipStream_t)stream), "tfc_colsum");
+  REQUIRE(x && out && rows > 0 && C % ue == 0, "bad args");
+  CHECK_HIP(tfc_launch_colsum(dt, x, rows, pitch, C, out, part_ws, (hipStream_t)stream), "tfc_colsum");
   return 0;
 }
 extern "C" int tfc_cast(void* stream, int dt, int to_f32, const void* x, void* y, long long n) {
@@ -718,14 +725,9 @@ extern "C" int tfc_axpby(void* stream, float* out, const float* x, const float* 
   return 0;
 }
 
-extern "C" int tfc_spectral_norm_step(void* stream, const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter) {
-  REQUIRE(W && u && v && sigma2 && ws && R > 0 && K > 0, "bad args");
-  CHECK_HIP(tfc_launch_sn_step(W, u, v, sigma2, ws, R, K, power_iter, 1e-12f, (hipStream_t)stream), "tfc_spectral_norm_step");
-  return 0;
-}
 extern "C" size_t tfc_spectral_norm_batched_ws_floats(int nlayers, const int* R, const int* K) {
-  size_t n = 0;
-  for (int i = 0; i < nlayers; ++i) n += (size_t)R[i] + K[i];
+  size_t n = 0;                                                   // per layer: (R / 32 row-block partials of W^T u) x K  +  s = W v (R)
+  for (int i = 0; i < nlayers; ++i) n += (size_t)((R[i] + 31) / 32) * K[i] + R[i];
   return n;
 }
 extern "C" int tfc_spectral_norm_step_batched(void* stream, int nlayers, const float* const* W, float* const* u, float* const* v,
@@ -734,25 +736,26 @@ extern "C" int tfc_spectral_norm_step_batched(void* stream, int nlayers, const f
   REQUIRE(nlayers >= 1 && nlayers <= 4 && W && u && v && sigma2 && R && K && ws, "bad args (1..4 layers)");
   SnBatch b{};
   b.n = nlayers;
-  size_t tot_k = 0, tot_r = 0;
-  for (int i = 0; i < nlayers; ++i) { tot_k += K[i]; tot_r += R[i]; }
-  float* tp = ws;                                                // [t_0 .. t_n | s_0 .. s_n]: the t part is zeroed every call
-  float* sp = ws + tot_k;
+  float* wp = ws;                                                // [t partials of layer 0 | s_0 | t partials of layer 1 | s_1 | ...]
   for (int i = 0; i < nlayers; ++i) {
     REQUIRE(W[i] && u[i] && v[i] && sigma2[i] && R[i] > 0 && K[i] > 0 && R[i] <= 4096, "bad layer %d", i);
     b.W[i] = W[i]; b.u[i] = u[i]; b.v[i] = v[i]; b.sigma2[i] = sigma2[i];
     b.us[i] = u_snap ? u_snap[i] : nullptr;
     b.vs[i] = v_snap ? v_snap[i] : nullptr;
     b.R[i] = R[i]; b.K[i] = K[i];
-    b.t[i] = tp; tp += K[i];
-    b.s[i] = sp; sp += R[i];
+    b.t[i] = wp; wp += (size_t)((R[i] + 31) / 32) * K[i];
+    b.s[i] = wp; wp += R[i];
   }
-  CHECK_HIP(tfc_launch_sn_step_batched(b, ws, tot_k * sizeof(float), power_iter, 1e-12f, (hipStream_t)stream), "tfc_spectral_norm_step_batched");
+  CHECK_HIP(tfc_launch_sn_step_batched(b, power_iter, 1e-12f, (hipStream_t)stream), "tfc_spectral_norm_step_batched");
   return 0;
+}
+extern "C" int tfc_spectral_norm_step(void* stream, const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter) {
+  REQUIRE(W && u && v && sigma2 && ws && R > 0 && K > 0, "bad args");
+  return tfc_spectral_norm_step_batched(stream, 1, &W, &u, &v, &sigma2, nullptr, nullptr, &R, &K, ws, power_iter);
 }
 extern "C" int tfc_spectral_norm_bwd(void* stream, const float* G, const float* W, const float* u, const float* v, const float* sigma2,
                                      float* ws, float* gout, int R, int K, int accumulate) {
-  REQUIRE(G && W && u && v && sigma2 && ws && gout, "bad args");
+  REQUIRE(G && W && u && v && sigma2 && ws && gout && (((uintptr_t)ws) & 7) == 0, "bad args (ws: 256 floats, 8-byte aligned)");
   CHECK_HIP(tfc_launch_sn_bwd(G, W, u, v, sigma2, ws, gout, R, K, accumulate, (hipStream_t)stream), "tfc_spectral_norm_bwd");
   return 0;
 }
@@ -795,9 +798,9 @@ extern "C" int tfc_affine_warp_fwd(void* stream, const float* src, const float* 
   return 0;
 }
 extern "C" int tfc_affine_warp_bwd(void* stream, const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C,
-                                   int H, int W) {
-  REQUIRE(src && theta && gout && dtheta && N > 0 && C > 0 && H > 1 && W > 1, "bad args");
-  CHECK_HIP(tfc_launch_affine_warp_bwd(src, theta, gout, dtheta, dsrc, N, C, H, W, (hipStream_t)stream), "tfc_affine_warp_bwd");
+                                   int H, int W, float* part_ws) {
+  REQUIRE(src && theta && gout && dtheta && part_ws && N > 0 && C > 0 && H > 1 && W > 1, "bad args");
+  CHECK_HIP(tfc_launch_affine_warp_bwd(src, theta, gout, dtheta, dsrc, part_ws, N, C, H, W, (hipStream_t)stream), "tfc_affine_warp_bwd");
   return 0;
 }
 extern "C" int tfc_morph_grad_fwd(void* stream, const float* x, float* out, uint8_t* arg, long long planes, int H, int W) {

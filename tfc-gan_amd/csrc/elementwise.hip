@@ -9,6 +9,56 @@
 //   relativistic BCE-with-logits, Adam, axpby, dropout-mask export.
 #include "common.h"
 
+// ---------------------------------------------------------------------------------------------------
+// Deterministic cross-workgroup sums (round 3). Every kernel that used to add its workgroup's partial into a small fp32 vector with
+// memory-side float atomics (InstanceNorm sums, their backward reductions, bias gradients) now STORES it,
+//     part[(g * nparts + p) * L + j]        g: image (or 0), p: the workgroup's FIXED slot, j: element,
+// and this kernel adds the slots in ONE fixed order: eight part-lanes take p = q, q + 8, ... ascending, then lanes 0..7 in order. Same inputs
+// => same bits, whatever order the producing workgroups ran in (float atomics gave run-to-run cos 0.991 on bf16 generator gradients).
+// out[g][j] += total (callers hand over zeroed or running sums, as they did to the atomics).
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+tfc_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int L) {
+  __shared__ float red[8][32];
+  const int jl = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl, g = blockIdx.y;
+  float s = 0.f;
+  if (j < L) {
+    const float* p0 = part + (size_t)g * nparts * L + j;
+#pragma unroll 4
+    for (int p = q; p < nparts; p += 8) s += p0[(size_t)p * L];
+  }
+  red[q][jl] = s;
+  __syncthreads();
+  if (q == 0 && j < L) {
+    float t = red[0][jl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += red[i][jl];
+    out[(size_t)g * L + j] += t;
+  }
+}
+// out[j] += sum_p part[p * stride + j], j < L <= 8 (the generator head's bias gradient: a handful of columns, up to 1024 slots): 32 part-lanes per column
+__global__ void __launch_bounds__(256)
+tfc_part_reduce_strided_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int stride, int L) {
+  __shared__ float red[8][32];
+  const int q = threadIdx.x & 31, j = threadIdx.x >> 5;
+  float s = 0.f;
+  if (j < L)
+    for (int p = q; p < nparts; p += 32) s += part[(size_t)p * stride + j];
+  red[j][q] = s;
+  __syncthreads();
+  if (q == 0 && j < L) {
+    float t = 0.f;
+    for (int i = 0; i < 32; ++i) t += red[j][i];
+    out[j] += t;
+  }
+}
+hipError_t tfc_launch_part_reduce(const float* part, float* out, int G, int nparts, int L, hipStream_t st) {
+  hipLaunchKernelGGL(tfc_part_reduce_kernel, dim3((L + 31) / 32, G), dim3(256), 0, st, part, out, nparts, L);
+  return hipGetLastError();
+}
+static inline bool part_fits(long long floats) { return floats <= (long long)TFC_PART_WS_FLOATS; }
+
 // BlurPool taps: [1,3,3,1]/8 per dimension (antialiased_cnns.BlurPool, filt_size 4), reflect pad (1,2).
 __device__ __forceinline__ float blur_w(int k) { return (k == 0 || k == 3) ? 0.125f : 0.375f; }
 __device__ __forceinline__ int reflect_idx(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
@@ -95,17 +145,17 @@ tfc_act_fwd_kernel(const ActParams p, const T* __restrict__ x, const float* __re
     }
   }
   if (STATS_OUT) {
-    // block reduction over the PPB pixel lanes, then one atomic per channel
+    // block reduction over the PPB pixel lanes (fixed order), then this workgroup's slot of the partial buffer: stats_out = part[n][blockIdx.x][C][2]
 #pragma unroll
     for (int e = 0; e < UE; ++e) { red[0][threadIdx.x * UE + e] = a1[e]; red[1][threadIdx.x * UE + e] = a2[e]; }
     __syncthreads();
     const int nch = CV * UE;                                      // == C
+    float2* slot = reinterpret_cast<float2*>(stats_out) + ((size_t)n * gridDim.x + blockIdx.x) * p.C;
     for (int c = threadIdx.x; c < nch; c += 256) {
       float s1 = 0.f, s2 = 0.f;
       const int ccv = c / UE, ce = c % UE;
       for (int q = 0; q < PPB; ++q) { s1 += red[0][(q * CV + ccv) * UE + ce]; s2 += red[1][(q * CV + ccv) * UE + ce]; }
-      atomicAdd(&stats_out[((size_t)n * p.C + c) * 2 + 0], s1);
-      atomicAdd(&stats_out[((size_t)n * p.C + c) * 2 + 1], s2);
+      slot[c] = make_float2(s1, s2);
     }
   }
 }
@@ -337,10 +387,9 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
       float s1 = 0.f, s2 = 0.f;
       const int ccv = c / UE, ce = c % UE;
       for (int q = 0; q < PPB; ++q) { s1 += red[0][(q * CV + ccv) * UE + ce]; s2 += red[1][(q * CV + ccv) * UE + ce]; }
-      atomicAdd(&rstats[((size_t)n * p.C + c) * 2 + 0], s1);
-      atomicAdd(&rstats[((size_t)n * p.C + c) * 2 + 1], s2);
+      reinterpret_cast<float2*>(rstats)[((size_t)n * gridDim.x + blockIdx.x) * p.C + c] = make_float2(s1, s2);   // rstats = part[n][blockIdx.x][C][2]
     }
-  } else if (MODE == 0 && rstats) {                              // rstats = float[N][C]: per-image column sums of dx (bias gradient)
+  } else if (MODE == 0 && rstats) {                              // rstats = part[n][blockIdx.x][C]: per-image column sums of dx (bias gradient)
 #pragma unroll
     for (int e = 0; e < UE; ++e) red[0][threadIdx.x * UE + e] = a1[e];
     __syncthreads();
@@ -349,7 +398,7 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
       float s1 = 0.f;
       const int ccv = c / UE, ce = c % UE;
       for (int q = 0; q < PPB; ++q) s1 += red[0][(q * CV + ccv) * UE + ce];
-      atomicAdd(&rstats[(size_t)n * p.C + c], s1);
+      rstats[((size_t)n * gridDim.x + blockIdx.x) * p.C + c] = s1;
     }
   }
 }
@@ -513,12 +562,9 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
       float s1 = 0.f, s2 = 0.f;
       const int ccv = c / UE, ce = c % UE;
       for (int q = 0; q < PL; ++q) { s1 += red[(q * CVS + ccv) * UE + ce]; s2 += red[256 * UE + (q * CVS + ccv) * UE + ce]; }
-      if (MODE == 1) {
-        atomicAdd(&rstats[((size_t)n * p.C + c0 + c) * 2 + 0], s1);
-        atomicAdd(&rstats[((size_t)n * p.C + c0 + c) * 2 + 1], s2);
-      } else {
-        atomicAdd(&rstats[(size_t)n * p.C + c0 + c], s1);
-      }
+      const size_t slot = ((size_t)n * gridDim.x + blockIdx.x) * p.C + c0 + c;   // rstats = part[n][tile][C]([2]): summed in a fixed order by tfc_part_reduce_kernel
+      if (MODE == 1) reinterpret_cast<float2*>(rstats)[slot] = make_float2(s1, s2);
+      else rstats[slot] = s1;
     }
   }
 }
@@ -643,53 +689,62 @@ tfc_blur1_kernel(const ActParams p, const T* __restrict__ src, int src_pitch, T*
       float s1 = 0.f, s2 = 0.f;
       const int ccv = c / UE, ce = c % UE;
       for (int q = 0; q < PL; ++q) { s1 += red[(q * CVS + ccv) * UE + ce]; s2 += red[256 * UE + (q * CVS + ccv) * UE + ce]; }
-      atomicAdd(&stats_out[((size_t)n * p.C + c0 + c) * 2 + 0], s1);
-      atomicAdd(&stats_out[((size_t)n * p.C + c0 + c) * 2 + 1], s2);
+      reinterpret_cast<float2*>(stats_out)[((size_t)n * gridDim.x + blockIdx.x) * p.C + c0 + c] = make_float2(s1, s2);   // part[n][tile][C][2]
     }
   }
 }
 template <typename T>
-static bool blur1_launch(const ActParams& p, const void* src, int src_pitch, void* dst, int dst_pitch, float* stats_out, int transpose,
+static bool blur1_launch(const ActParams& p, const void* src, int src_pitch, void* dst, int dst_pitch, float* stats_out, float* part_ws, int transpose,
                          hipStream_t st) {
   constexpr int UE = ElemTraits<T>::UE;
   if (p.C % (8 * UE) != 0 || p.H < 4 || p.W < 4) return false;
   const int tiles_x = (p.W + 31) / 32, tiles_y = (p.H + 7) / 8;
   const dim3 grid(tiles_x * tiles_y, p.N, p.C / (8 * UE));
   const size_t lds = (size_t)12 * 36 * 8 * 16 + (8 + 32) * 8 * sizeof(float);
-  if (stats_out)
-    hipLaunchKernelGGL((tfc_blur1_kernel<T, true>), grid, dim3(256), lds, st, p, (const T*)src, src_pitch, (T*)dst, dst_pitch, stats_out, transpose, tiles_x);
-  else
+  if (stats_out) {
+    if (!part_ws || !part_fits((long long)grid.x * p.N * p.C * 2)) return false;   // the generic kernel's launcher reports the error
+    hipLaunchKernelGGL((tfc_blur1_kernel<T, true>), grid, dim3(256), lds, st, p, (const T*)src, src_pitch, (T*)dst, dst_pitch, part_ws, transpose, tiles_x);
+    tfc_launch_part_reduce(part_ws, stats_out, p.N, grid.x, 2 * p.C, st);
+  } else
     hipLaunchKernelGGL((tfc_blur1_kernel<T, false>), grid, dim3(256), lds, st, p, (const T*)src, src_pitch, (T*)dst, dst_pitch, stats_out, transpose, tiles_x);
   return true;
 }
 
-// column sums: out[c] += sum over rows of x[row][c]   (bias gradients)
+// column sums: out[c] += sum over rows of x[row][c]   (bias gradients). Deterministic: a workgroup owns 8 channel vectors, its 32 row-lanes take rows
+// r, r + 32, ... ascending and meet in LDS in lane order; with many rows (and a partial buffer) the rows are first split over blockIdx.y and the
+// slots summed by tfc_part_reduce_kernel.
 template <typename T>
 __global__ void __launch_bounds__(256)
-tfc_colsum_kernel(const T* __restrict__ x, long long rows, int pitch, int C, float* out) {
+tfc_colsum_kernel(const T* __restrict__ x, long long rows, int pitch, int C, float* out, int to_part) {
   constexpr int UE = ElemTraits<T>::UE;
-  __shared__ float red[2048];
+  __shared__ float red[32][8 * UE];
   const int CV = C / UE;
-  const int PPB = 256 / CV;
-  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  const int cvl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int cv = blockIdx.x * 8 + cvl;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = (long long)blockIdx.y * per, r1 = (r0 + per) < rows ? (r0 + per) : rows;
   float a[UE];
 #pragma unroll
   for (int e = 0; e < UE; ++e) a[e] = 0.f;
-  if (pl < PPB)
-    for (long long r = (long long)blockIdx.x * PPB + pl; r < rows; r += (long long)gridDim.x * PPB) {
+  if (cv < CV)
+    for (long long r = r0 + rl; r < r1; r += 32) {
       float v[UE];
       unpack16<T>(*reinterpret_cast<const uint4*>(x + r * pitch + cv * UE), v);
 #pragma unroll
       for (int e = 0; e < UE; ++e) a[e] += v[e];
     }
 #pragma unroll
-  for (int e = 0; e < UE; ++e) red[threadIdx.x * UE + e] = a[e];
+  for (int e = 0; e < UE; ++e) red[rl][cvl * UE + e] = a[e];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    const int ccv = c / UE, ce = c % UE;
-    for (int q = 0; q < PPB; ++q) s += red[(q * CV + ccv) * UE + ce];
-    atomicAdd(&out[c], s);
+  if (threadIdx.x < 8 * UE) {
+    const int c = blockIdx.x * 8 * UE + threadIdx.x;
+    if (c < C) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < 32; ++q) s += red[q][threadIdx.x];
+      if (to_part) out[(size_t)blockIdx.y * C + c] = s;           // out = part[blockIdx.y][C]
+      else out[c] += s;
+    }
   }
 }
 
@@ -758,7 +813,7 @@ tfc_tanh_bwd_pack_kernel(const float* __restrict__ g, const float* __restrict__ 
     *reinterpret_cast<uint4*>(o) = pack16<T>(v);
     if (sizeof(T) == 4) *reinterpret_cast<uint4*>(o + 4) = pack16<T>(v + 4);
   }
-  if (dbias) {                                                   // few workgroups => few same-address atomics (they serialise at ~12 ns each)
+  if (dbias) {                                                   // dbias = part[blockIdx.x][4]: summed in a fixed order by tfc_part_reduce_kernel
 #pragma unroll
     for (int c = 0; c < 4; ++c) red[c][threadIdx.x] = bs[c];
     __syncthreads();
@@ -767,7 +822,7 @@ tfc_tanh_bwd_pack_kernel(const float* __restrict__ g, const float* __restrict__ 
       for (int c = 0; c < 4; ++c) {
         float sred = red[c][threadIdx.x] + red[c][threadIdx.x + 64] + red[c][threadIdx.x + 128] + red[c][threadIdx.x + 192];
         sred = wave_sum(sred);
-        if (threadIdx.x == 0 && c < C) atomicAdd(&dbias[c], sred);
+        if (threadIdx.x == 0) dbias[(size_t)blockIdx.x * 4 + c] = c < C ? sred : 0.f;
       }
     }
   }
@@ -777,53 +832,6 @@ tfc_tanh_bwd_pack_kernel(const float* __restrict__ g, const float* __restrict__ 
 // spectral norm (torch.nn.utils.parametrizations.spectral_norm, 1 power iteration per training forward):
 //   u <- normalize(W v);  v <- normalize(W^T u);  sigma = u . (W v)        W: [R][K] fp32 row-major
 // ---------------------------------------------------------------------------------------------------
-// s[r] = sum_k W[r][k] v[k]   (one wave per row)
-__global__ void __launch_bounds__(256) tfc_sn_mv_kernel(const float* __restrict__ W, const float* __restrict__ v, float* s, int R, int K) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= R) return;
-  float a = 0.f;
-  for (int k = lane; k < K; k += 64) a += W[(size_t)row * K + k] * v[k];
-  a = wave_sum(a);
-  if (lane == 0) s[row] = a;
-}
-// t[k] = sum_r W[r][k] u[r]   (thread per column, rows split over blockIdx.y, fp32 atomics)
-__global__ void __launch_bounds__(256) tfc_sn_mtv_kernel(const float* __restrict__ W, const float* __restrict__ u, float* t, int R, int K, int rows_per) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= K) return;
-  const int r0 = blockIdx.y * rows_per;
-  const int r1 = min(R, r0 + rows_per);
-  float a = 0.f;
-  for (int r = r0; r < r1; ++r) a += W[(size_t)r * K + k] * u[r];
-  atomicAdd(&t[k], a);
-}
-// out = x / max(||x||, eps); optionally sigma = dot(out, x2) (x2 may alias x), inv_sigma = 1/sigma. single block.
-__global__ void __launch_bounds__(1024) tfc_sn_normalize_kernel(const float* __restrict__ x, float* out, int n, float eps) {
-  __shared__ float red[16];
-  float a = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) a += x[i] * x[i];
-  a = wave_sum(a);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-  __syncthreads();
-  float tot = 0.f;
-  for (int i = 0; i < 16; ++i) tot += red[i];
-  const float inv = 1.f / fmaxf(sqrtf(tot), eps);
-  for (int i = threadIdx.x; i < n; i += 1024) out[i] = x[i] * inv;
-}
-__global__ void __launch_bounds__(1024) tfc_sn_sigma_kernel(const float* __restrict__ u, const float* __restrict__ s, int n, float* sigma2) {
-  __shared__ float red[16];
-  float a = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) a += u[i] * s[i];
-  a = wave_sum(a);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float tot = 0.f;
-    for (int i = 0; i < 16; ++i) tot += red[i];
-    sigma2[0] = tot;
-    sigma2[1] = 1.f / tot;
-  }
-}
 // ---- batched form: all spectral-normed layers of one Discriminator1 forward in 3 launches (blockIdx.y = layer) ----
 struct SnBatch {
   const float* W[4];
@@ -833,7 +841,6 @@ struct SnBatch {
   int R[4], K[4];
   int n;
 };
-static __device__ TfcRedSlot g_sn_slot[4];
 
 __device__ __forceinline__ float block_sum_256(float a, float* red4) {
   a = wave_sum(a);
@@ -860,7 +867,9 @@ __global__ void __launch_bounds__(256) tfc_snb_mv_kernel(const SnBatch b) {
   a = wave_sum(a);
   if (lane == 0) b.s[L][row] = a;
 }
-// u = s / max(|s|, eps) (norm recomputed per workgroup: R <= 512); t += W^T u over this workgroup's 32 rows
+// u = s / max(|s|, eps) (norm recomputed per workgroup: R <= 4096); t_part[z] = W^T u over this workgroup's 32 rows (z = blockIdx.z) -- plain stores,
+// summed over z in a fixed order by tfc_snb_vnorm_kernel (the float atomics this replaces made sigma, and with it every discriminator activation,
+// differ from run to run)
 __global__ void __launch_bounds__(256) tfc_snb_mtv_kernel(const SnBatch b, float eps) {
   __shared__ float red4[4];
   __shared__ float ush[32];
@@ -883,77 +892,78 @@ __global__ void __launch_bounds__(256) tfc_snb_mtv_kernel(const SnBatch b, float
   const int r1 = min(R, r0 + 32);
   float acc = 0.f;
   for (int r = r0; r < r1; ++r) acc += W[(size_t)r * K + k] * ush[r - r0];
-  atomicAdd(&b.t[L][k], acc);
+  b.t[L][(size_t)blockIdx.z * K + k] = acc;
 }
-// v = t / max(|t|, eps) (when power_iter); sigma = u . (W v)
-__global__ void __launch_bounds__(256) tfc_snb_sigma_kernel(const SnBatch b, float eps, int power_iter) {
-  __shared__ float red4[4];
-  const int L = blockIdx.y, R = b.R[L], K = b.K[L];
-  const int nblk = (R + 3) / 4;
-  if ((int)blockIdx.x >= nblk) return;
-  float inv = 1.f;
-  const float* vin = power_iter ? b.t[L] : b.v[L];
-  if (power_iter) {
-    float a = 0.f;
-    for (int i = threadIdx.x; i < K; i += 256) { const float x = vin[i]; a += x * x; }
-    inv = 1.f / fmaxf(sqrtf(block_sum_256(a, red4)), eps);
-    if (blockIdx.x == 0)
-      for (int i = threadIdx.x; i < K; i += 256) { const float x = vin[i] * inv; b.v[L][i] = x; if (b.vs[L]) b.vs[L][i] = x; }
-  } else if (blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < K; i += 256) if (b.vs[L]) b.vs[L][i] = vin[i];
-    for (int i = threadIdx.x; i < R; i += 256) if (b.us[L]) b.us[L][i] = b.u[L][i];
+// one workgroup per layer: t = sum_z t_part[z] (z ascending), v = t / max(|t|, eps), sigma = t . v  (= u . (W v) with the u, v just computed:
+// u^T W v = (W^T u)^T v; torch evaluates the left form, the two agree to fp32 round-off and this one needs no third pass over W)
+__global__ void __launch_bounds__(1024) tfc_snb_vnorm_kernel(const SnBatch b, float eps) {
+  __shared__ float red[16];
+  const int L = blockIdx.x, R = b.R[L], K = b.K[L];
+  const int nz = (R + 31) / 32;
+  const float* tp = b.t[L];
+  float a = 0.f;
+  for (int k = threadIdx.x; k < K; k += 1024) {
+    float t = 0.f;
+    for (int z = 0; z < nz; ++z) t += tp[(size_t)z * K + k];
+    a += t * t;
   }
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float part = 0.f;
-  if (row < R) {
-    const float* W = b.W[L] + (size_t)row * K;
-    float a = 0.f;
-    if ((K & 3) == 0) {
-      const float4* W4 = reinterpret_cast<const float4*>(W);
-      const float4* v4 = reinterpret_cast<const float4*>(vin);
-      for (int k = lane; k < (K >> 2); k += 64) { const float4 w = W4[k], x = v4[k]; a += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w; }
-    } else {
-      for (int k = lane; k < K; k += 64) a += W[k] * vin[k];
-    }
-    a = wave_sum(a) * inv;
-    // u of this row: written by the mtv kernel of this call (power_iter) or the stored buffer
-    part = a * b.u[L][row];
-  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (lane == 0) red4[threadIdx.x >> 6] = part;
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tot += red[i];
+  const float inv = 1.f / fmaxf(sqrtf(tot), eps);
+  for (int k = threadIdx.x; k < K; k += 1024) {
+    float t = 0.f;
+    for (int z = 0; z < nz; ++z) t += tp[(size_t)z * K + k];
+    const float x = t * inv;
+    b.v[L][k] = x;
+    if (b.vs[L]) b.vs[L][k] = x;
+  }
+  if (threadIdx.x == 0) {
+    const float sg = tot * inv;
+    b.sigma2[L][0] = sg;
+    b.sigma2[L][1] = 1.f / sg;
+  }
+}
+// no power iteration (eval-mode forward): sigma = u . s with s = W v from tfc_snb_mv_kernel, summed in a fixed order; snapshots of the stored u, v
+__global__ void __launch_bounds__(1024) tfc_snb_sigma_kernel(const SnBatch b) {
+  __shared__ float red[16];
+  const int L = blockIdx.x, R = b.R[L], K = b.K[L];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < R; i += 1024) a += b.u[L][i] * b.s[L][i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
   if (threadIdx.x == 0) {
-    TfcRedSlot* slot = &g_sn_slot[L];
-    atomicAdd(&slot->acc, (double)red4[0] + (double)red4[1] + (double)red4[2] + (double)red4[3]);
-    __threadfence();
-    const unsigned tk = atomicAdd(&slot->cnt, 1u);
-    if (tk == (unsigned)nblk - 1) {
-      __threadfence();
-      const double tot = atomicAdd(&slot->acc, 0.0);
-      atomicExch(reinterpret_cast<unsigned long long*>(&slot->acc), 0ull);
-      atomicExch(&slot->cnt, 0u);
-      b.sigma2[L][0] = (float)tot;
-      b.sigma2[L][1] = (float)(1.0 / tot);
-    }
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    b.sigma2[L][0] = tot;
+    b.sigma2[L][1] = 1.f / tot;
   }
+  for (int i = threadIdx.x; i < K; i += 1024) if (b.vs[L]) b.vs[L][i] = b.v[L][i];
+  for (int i = threadIdx.x; i < R; i += 1024) if (b.us[L]) b.us[L][i] = b.u[L][i];
 }
 
-hipError_t tfc_launch_sn_step_batched(const SnBatch& b, float* ws_t, size_t t_bytes, int power_iter, float eps, hipStream_t st) {
+hipError_t tfc_launch_sn_step_batched(const SnBatch& b, int power_iter, float eps, hipStream_t st) {
   int maxR = 0, maxK = 0;
   for (int i = 0; i < b.n; ++i) { maxR = b.R[i] > maxR ? b.R[i] : maxR; maxK = b.K[i] > maxK ? b.K[i] : maxK; }
+  hipLaunchKernelGGL(tfc_snb_mv_kernel, dim3((maxR + 3) / 4, b.n), dim3(256), 0, st, b);
   if (power_iter) {
-    hipLaunchKernelGGL(tfc_snb_mv_kernel, dim3((maxR + 3) / 4, b.n), dim3(256), 0, st, b);
-    hipError_t e = hipMemsetAsync(ws_t, 0, t_bytes, st);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tfc_snb_mtv_kernel, dim3((maxK + 255) / 256, b.n, (maxR + 31) / 32), dim3(256), 0, st, b, eps);
+    hipLaunchKernelGGL(tfc_snb_vnorm_kernel, dim3(b.n), dim3(1024), 0, st, b, eps);
+  } else {
+    hipLaunchKernelGGL(tfc_snb_sigma_kernel, dim3(b.n), dim3(1024), 0, st, b);
   }
-  hipLaunchKernelGGL(tfc_snb_sigma_kernel, dim3((maxR + 3) / 4, b.n), dim3(256), 0, st, b, eps, power_iter);
   return hipGetLastError();
 }
 
 // spectral-norm backward: gw = (G - (sum G*Wsn) u v^T) / sigma, Wsn = W/sigma.  pass 1: dot += sum G*W ; pass 2: apply
-static __device__ TfcRedSlot g_dot_slot;
-__global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* out) {
+// dot = sum a*b: per-workgroup partials (doubles) to ws, then ONE workgroup adds them in slot order (tfc_dot_fin_kernel) -- the scalar feeds every
+// element of the weight gradient, so it must not depend on the order in which workgroups finish
+__global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, double* part) {
   __shared__ float red[4];
   float s = 0.f;
   if ((n & 3) == 0) {
@@ -969,16 +979,25 @@ __global__ void __launch_bounds__(256) tfc_dot_kernel(const float* __restrict__ 
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) tfc_block_commit(&g_dot_slot, (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3], out, true);   // out[0] = total: no memset launch
+  if (threadIdx.x == 0) part[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
 }
 __global__ void __launch_bounds__(256) tfc_sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
-                                                                const float* __restrict__ sigma2, const float* __restrict__ gw_dot,
+                                                                const float* __restrict__ sigma2, const double* __restrict__ dot_part, int nparts,
                                                                 float* gout, int R, int K, int accumulate) {
+  __shared__ float dsh;
+  if (threadIdx.x < 64) {                                        // the dot product: <= 128 partials, two per lane, then a fixed butterfly
+    double d = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) d += dot_part[p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (threadIdx.x == 0) dsh = (float)d;
+  }
+  __syncthreads();
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)R * K) return;
   const int r = (int)(i / K), k = (int)(i - (long long)r * K);
   const float inv = sigma2[1];
-  const float dotws = gw_dot[0] * inv;                           // sum G * Wsn = (sum G*W)/sigma
+  const float dotws = dsh * inv;                                 // sum G * Wsn = (sum G*W)/sigma
   const float val = (G[i] - dotws * u[r] * v[k]) * inv;
   gout[i] = accumulate ? gout[i] + val : val;
 }
@@ -1154,7 +1173,7 @@ static inline dim3 act_grid(int npix, int C, int ue, int N) {
 }
 
 template <typename T>
-static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st) {
+static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, float* part_ws, hipStream_t st) {
   if (p.pool == 2 && !stats_out) {
     const dim3 g2 = act_grid(((p.Ho + 1) / 2) * ((p.Wo + 1) / 2), p.C, ElemTraits<T>::UE, p.N);
     if (!p.norm && p.slope == 1.f)
@@ -1164,17 +1183,19 @@ static hipError_t act_fwd_t(const ActParams& p, const void* x, const float* stat
     return hipGetLastError();
   }
   if (p.pool == 1 && !p.norm && p.slope == 1.f && !p.drop_thresh24 &&
-      blur1_launch<T>(p, x, p.x_pitch, out, p.o_pitch, stats_out, 0, st))        // pure blur of the up path: tiled kernel
+      blur1_launch<T>(p, x, p.x_pitch, out, p.o_pitch, stats_out, part_ws, 0, st))        // pure blur of the up path: tiled kernel
     return hipGetLastError();
   const dim3 grid = act_grid(p.Ho * p.Wo, p.C, ElemTraits<T>::UE, p.N);
-  if (stats_out)
-    hipLaunchKernelGGL((tfc_act_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)x, stats, (T*)out, stats_out);
-  else
+  if (stats_out) {
+    if (!part_ws || !part_fits((long long)grid.x * p.N * p.C * 2)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((tfc_act_fwd_kernel<T, true>), grid, dim3(256), 0, st, p, (const T*)x, stats, (T*)out, part_ws);
+    return tfc_launch_part_reduce(part_ws, stats_out, p.N, grid.x, 2 * p.C, st);
+  } else
     hipLaunchKernelGGL((tfc_act_fwd_kernel<T, false>), grid, dim3(256), 0, st, p, (const T*)x, stats, (T*)out, stats_out);
   return hipGetLastError();
 }
-hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, hipStream_t st) {
-  return dt == TFC_DT_BF16 ? act_fwd_t<bf16_t>(p, x, stats, out, stats_out, st) : act_fwd_t<float>(p, x, stats, out, stats_out, st);
+hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, float* part_ws, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? act_fwd_t<bf16_t>(p, x, stats, out, stats_out, part_ws, st) : act_fwd_t<float>(p, x, stats, out, stats_out, part_ws, st);
 }
 template <typename T, int MODE>
 static void act_bwd_launch(const dim3& grid, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats,
@@ -1188,7 +1209,11 @@ static void act_bwd_launch(const dim3& grid, const ActParams& p, const void* dou
 }
 template <typename T>
 static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats,
-                            void* dx, int use_x, int dx_pitch, hipStream_t st) {
+                            void* dx, int use_x, int dx_pitch, float* part_ws, hipStream_t st) {
+  // reductions (mode 1: the two InstanceNorm-backward sums per (image, channel); mode 0 with rstats: per-image bias-gradient sums) leave each workgroup
+  // as one slot of part_ws and are added in a fixed order behind the kernel
+  const int red_l = mode == 1 ? 2 * p.C : ((mode == 0 && rstats) ? p.C : 0);
+  if (red_l && !part_ws) return hipErrorInvalidValue;
   if (p.pool == 2 && use_x) {                                     // tiled stride-2 backward (16 x 32 input pixels x 64 channels per workgroup)
     constexpr int UE = ElemTraits<T>::UE;
     const int cslice = p.C < 64 ? p.C : 64;
@@ -1198,36 +1223,47 @@ static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, cons
       size_t lds = (size_t)11 * 19 * (cslice / UE) * 16;        // pooled-gradient window, reused as reduction scratch ...
       if (lds < 2 * 256 * UE * sizeof(float)) lds = 2 * 256 * UE * sizeof(float);
       lds += (16 + 32) * 16;                                      // ... + the per-row / per-column tap-weight tables
+      if (red_l && !part_fits((long long)grid.x * p.N * red_l)) return hipErrorInvalidValue;
       if (mode == 0)                                              // mode 0 is only valid without normalisation, modes 1/2 only with it
-        hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 0, false>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, dx_pitch, tiles_x, cslice);
+        hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 0, false>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats ? part_ws : nullptr, (T*)dx, dx_pitch, tiles_x, cslice);
       else if (mode == 1)
-        hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 1, true>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, dx_pitch, tiles_x, cslice);
+        hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 1, true>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, part_ws, (T*)dx, dx_pitch, tiles_x, cslice);
       else
         hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<T, 2, true>), grid, dim3(256), lds, st, p, (const T*)dout, (const T*)x, stats, rstats, (T*)dx, dx_pitch, tiles_x, cslice);
+      if (red_l) return tfc_launch_part_reduce(part_ws, rstats, p.N, grid.x, red_l, st);
       return hipGetLastError();
     }
   }
   if (p.pool == 1 && mode == 0 && !use_x && !rstats && !p.drop_thresh24 &&
-      blur1_launch<T>(p, dout, p.o_pitch, dx, dx_pitch, nullptr, 1, st))          // transpose of the pure blur
+      blur1_launch<T>(p, dout, p.o_pitch, dx, dx_pitch, nullptr, nullptr, 1, st))          // transpose of the pure blur
     return hipGetLastError();
   const dim3 grid = act_grid(p.H * p.W, p.C, ElemTraits<T>::UE, p.N);
-  if (mode == 0) act_bwd_launch<T, 0>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
-  else if (mode == 1) act_bwd_launch<T, 1>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
+  if (red_l && !part_fits((long long)grid.x * p.N * red_l)) return hipErrorInvalidValue;
+  if (mode == 0) act_bwd_launch<T, 0>(grid, p, dout, x, stats, rstats ? part_ws : nullptr, dx, use_x, dx_pitch, st);
+  else if (mode == 1) act_bwd_launch<T, 1>(grid, p, dout, x, stats, part_ws, dx, use_x, dx_pitch, st);
   else act_bwd_launch<T, 2>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
+  if (red_l) return tfc_launch_part_reduce(part_ws, rstats, p.N, grid.x, red_l, st);
   return hipGetLastError();
 }
 hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats,
-                              float* rstats, void* dx, int use_x, int dx_pitch, hipStream_t st) {
-  return dt == TFC_DT_BF16 ? act_bwd_t<bf16_t>(mode, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st)
-                           : act_bwd_t<float>(mode, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
+                              float* rstats, void* dx, int use_x, int dx_pitch, float* part_ws, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? act_bwd_t<bf16_t>(mode, p, dout, x, stats, rstats, dx, use_x, dx_pitch, part_ws, st)
+                           : act_bwd_t<float>(mode, p, dout, x, stats, rstats, dx, use_x, dx_pitch, part_ws, st);
 }
-hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, hipStream_t st) {
+hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, float* part_ws, hipStream_t st) {
   const int ue = dt == TFC_DT_BF16 ? 8 : 4;
-  const int ppb = 256 / (C / ue);
-  long long nb = (rows + ppb - 1) / ppb;
-  if (nb > 2048) nb = 2048;
-  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_colsum_kernel<bf16_t>), dim3((int)nb), dim3(256), 0, st, (const bf16_t*)x, rows, pitch, C, out);
-  else hipLaunchKernelGGL((tfc_colsum_kernel<float>), dim3((int)nb), dim3(256), 0, st, (const float*)x, rows, pitch, C, out);
+  const int nbx = (C / ue + 7) / 8;
+  int ny = 1;                                                     // row split: only when there are enough rows to matter and a partial buffer to split into
+  if (part_ws && rows >= 4096) {
+    ny = (int)((rows + 1023) / 1024);
+    const int cap = 2048 / nbx > 1 ? 2048 / nbx : 1;
+    if (ny > cap) ny = cap;
+    if (!part_fits((long long)ny * C)) ny = 1;
+  }
+  float* dst = ny > 1 ? part_ws : out;
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_colsum_kernel<bf16_t>), dim3(nbx, ny), dim3(256), 0, st, (const bf16_t*)x, rows, pitch, C, dst, ny > 1);
+  else hipLaunchKernelGGL((tfc_colsum_kernel<float>), dim3(nbx, ny), dim3(256), 0, st, (const float*)x, rows, pitch, C, dst, ny > 1);
+  if (ny > 1) return tfc_launch_part_reduce(part_ws, out, 1, ny, C, st);
   return hipGetLastError();
 }
 hipError_t tfc_launch_pack_nhwc8(int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int HW, hipStream_t st) {
@@ -1244,40 +1280,29 @@ hipError_t tfc_launch_unpack_nchw(int dt, const void* in, int pitch, int c0, int
   else hipLaunchKernelGGL((tfc_unpack_nchw_kernel<float>), grid, dim3(256), 0, st, (const float*)in, pitch, c0, C, out, N, HW, alpha, beta);
   return hipGetLastError();
 }
-hipError_t tfc_launch_tanh_bwd_pack(int dt, const float* g, const float* y, void* out, float* dbias, int N, int C, int HW, hipStream_t st) {
+hipError_t tfc_launch_tanh_bwd_pack(int dt, const float* g, const float* y, void* out, float* dbias, float* part_ws, int N, int C, int HW, hipStream_t st) {
   const long long tot = (long long)N * HW;
   long long nbk = (tot + 255) / 256;
   if (nbk > 1024) nbk = 1024;
   const dim3 grid((unsigned)nbk);
-  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<bf16_t>), grid, dim3(256), 0, st, g, y, (bf16_t*)out, dbias, N, C, HW);
-  else hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<float>), grid, dim3(256), 0, st, g, y, (float*)out, dbias, N, C, HW);
-  return hipGetLastError();
-}
-// one power iteration; ws: float[R + K] scratch (s | t). u:[R] v:[K] updated in place; sigma2: {sigma, 1/sigma}
-hipError_t tfc_launch_sn_step(const float* W, float* u, float* v, float* sigma2, float* ws, int R, int K, int power_iter, float eps, hipStream_t st) {
-  float* s = ws;
-  float* t = ws + R;
-  if (power_iter) {
-    hipLaunchKernelGGL(tfc_sn_mv_kernel, dim3((R + 3) / 4), dim3(256), 0, st, W, v, s, R, K);
-    hipLaunchKernelGGL(tfc_sn_normalize_kernel, dim3(1), dim3(1024), 0, st, s, u, R, eps);
-    hipError_t e = hipMemsetAsync(t, 0, sizeof(float) * K, st);
-    if (e != hipSuccess) return e;
-    const int rows_per = 32;
-    hipLaunchKernelGGL(tfc_sn_mtv_kernel, dim3((K + 255) / 256, (R + rows_per - 1) / rows_per), dim3(256), 0, st, W, u, t, R, K, rows_per);
-    hipLaunchKernelGGL(tfc_sn_normalize_kernel, dim3(1), dim3(1024), 0, st, t, v, K, eps);
+  if (dbias && !part_ws) return hipErrorInvalidValue;
+  float* part = dbias ? part_ws : nullptr;                        // part[workgroup][4]
+  if (dt == TFC_DT_BF16) hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<bf16_t>), grid, dim3(256), 0, st, g, y, (bf16_t*)out, part, N, C, HW);
+  else hipLaunchKernelGGL((tfc_tanh_bwd_pack_kernel<float>), grid, dim3(256), 0, st, g, y, (float*)out, part, N, C, HW);
+  if (dbias) {                                                    // dbias[c] += sum over the workgroup slots, c < C (slot stride 4)
+    hipLaunchKernelGGL(tfc_part_reduce_strided_kernel, dim3(1), dim3(256), 0, st, part, dbias, (int)nbk, 4, C);
   }
-  hipLaunchKernelGGL(tfc_sn_mv_kernel, dim3((R + 3) / 4), dim3(256), 0, st, W, v, s, R, K);
-  hipLaunchKernelGGL(tfc_sn_sigma_kernel, dim3(1), dim3(1024), 0, st, u, s, R, sigma2);
   return hipGetLastError();
 }
-// gout = (G - (sum G*W)/sigma * u v^T)/sigma ; dot_ws: 1 float scratch
+// gout = (G - (sum G*W)/sigma * u v^T)/sigma ; dot_ws: 2 * TFC_SN_BWD_PARTS floats of scratch (the dot product's per-workgroup partials, as doubles)
 hipError_t tfc_launch_sn_bwd(const float* G, const float* W, const float* u, const float* v, const float* sigma2, float* dot_ws,
                              float* gout, int R, int K, int accumulate, hipStream_t st) {
   const long long n = (long long)R * K;
   int nb = (int)((n + 1023) / 1024);
-  if (nb > 128) nb = 128;                                        // every workgroup ends in ONE atomic on the same address (~12 ns each, serialised)
-  hipLaunchKernelGGL(tfc_dot_kernel, dim3(nb), dim3(256), 0, st, G, W, n, dot_ws);
-  hipLaunchKernelGGL(tfc_sn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, u, v, sigma2, dot_ws, gout, R, K, accumulate);
+  if (nb > TFC_SN_BWD_PARTS) nb = TFC_SN_BWD_PARTS;
+  double* part = reinterpret_cast<double*>(dot_ws);
+  hipLaunchKernelGGL(tfc_dot_kernel, dim3(nb), dim3(256), 0, st, G, W, n, part);
+  hipLaunchKernelGGL(tfc_sn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G, u, v, sigma2, part, nb, gout, R, K, accumulate);
   return hipGetLastError();
 }
 hipError_t tfc_launch_bce_rel(int dt, const void* a, const void* b, int n, int stride, float t1, float t2, int mode, float* loss, void* da, void* db, float gscale, hipStream_t st) {

@@ -320,12 +320,13 @@ tfc_igemm_kernel(const TfcGather d, const T* __restrict__ in, const uint4* __res
         }
       }
     }
-    if (flags & TFC_EP_STATS) {
+    if (flags & TFC_EP_STATS) {                                  // stats = part[img][tile * WM + wm][Nout][2] (plain stores; summed in a fixed order afterwards)
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (h == 0 && nok) {
-        atomicAdd(&stats[((size_t)img * d.Nout + n) * 2 + 0], s1);
-        atomicAdd(&stats[((size_t)img * d.Nout + n) * 2 + 1], s2);
+        const int tpi = d.tiles_y * d.tiles_x;                   // folded sub-pixel phases: every phase has its own tile slots
+        const size_t slot = (((size_t)img * (d.ph_n > 1 ? d.ph_n : 1) + phase) * tpi + (tyb * d.tiles_x + txb)) * WM + wm;
+        reinterpret_cast<float2*>(stats)[slot * d.Nout + n] = make_float2(s1, s2);
       }
     }
   }
@@ -473,8 +474,8 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   const int xtra = IL ? (128 * ROWP > buf_bytes ? 128 * ROWP - buf_bytes : 0) : 0;
   const int bstride = buf_bytes + xtra;                          // distance of the two halo buffers
   unsigned char* stage_fix = smem + 2 * buf_bytes;
-  float* sstat = reinterpret_cast<float*>(IL ? smem + 2 * buf_bytes + xtra : stage_fix + 128 * ROWP);   // [2][BN][2] statistics partials of the current / the previous tile (zero when unused)
-  float* sbias = sstat + 4 * BN;                                 // bias of EVERY output channel of the layer (nblkN * BN floats), loaded once
+  float* sstat = reinterpret_cast<float*>(IL ? smem + 2 * buf_bytes + xtra : stage_fix + 128 * ROWP);   // [4 waves][BN][2] statistics partials of the tile just stored (EP_STATS only)
+  float* sbias = sstat + ((flags & TFC_EP_STATS) ? 8 * BN : 0);  // bias of EVERY output channel of the layer (nblkN * BN floats), loaded once (EP_BIAS only)
 
   const int laneBase = ((2 * wm * MT + (r & 1)) * P + (r >> 1)) * 80 + h * 16;
   const unsigned lanepart = (unsigned)((IL ? wn : wn * NT) * 64 + lane) * 16u;
@@ -590,7 +591,6 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   const unsigned char* bptr = cur.wbase + lanepart + (size_t)BD * wstep_b;   // next fragment to request (per lane)
   if (flags & TFC_EP_BIAS)
     for (int n = tid; n < nblkN * BN; n += 256) sbias[n] = n < d.Nout ? bias[n] : 0.f;
-  for (int n = tid; n < 4 * BN; n += 256) sstat[n] = 0.f;
   halo_load(cur, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   halo_store(smem);
@@ -599,20 +599,19 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   TFC_STAMP_AT(1);
   int sc = 0;                                                    // running stage counter: halo buffer parity across tiles
 
-  // InstanceNorm statistics leave the workgroup one tile LATE: memory-side float atomics stay on the wave's vmcnt for ~3,000 cycles and vmcnt
-  // retires in order, so atomics issued at the end of a tile stall the first counted wait of the next tile's K loop for that long (measured:
-  // +6,000 cycles per tile). The tile's sums therefore wait in LDS (two parities) and wave 0 adds the PREVIOUS tile's sums to memory right
-  // after the K loop, where ~3,000 cycles of register-only epilogue work follow before the pipeline is drained anyway.
+  // InstanceNorm statistics. Deterministic (round 3): the four waves' sums of a tile go to FOUR LDS slots with plain stores (the LDS float atomics they
+  // replace added in arrival order), wave 0 adds the slots in wave order and STORES the tile's 2 * BN sums into the tile's own slot of the partial buffer
+  // stats = part[img][tile][Nout][2]; tfc_part_reduce_kernel adds the tiles in a fixed order behind this launch. The flush still happens one tile LATE,
+  // right after the next tile's K loop: every workgroup barrier of that loop lies between the slot writes and these reads, and the stores leave the
+  // wave's in-order vmcnt queue long before the epilogue drains it (the memory-side atomics of round 2 sat there for ~3,000 cycles each).
   float* stat_prev = nullptr;
   int stat_lim = 0, tcount = 0;
-  auto stat_flush = [&]() {                                       // wave 0; every workgroup barrier since the previous tile's LDS adds is behind us
+  auto stat_flush = [&]() {                                       // wave 0
     if (stat_prev && wave == 0) {
-      float* sp = sstat + ((tcount - 1) & 1) * 2 * BN;
 #pragma unroll
       for (int i = lane; i < 2 * BN; i += 64) {
-        const float v = sp[i];
-        sp[i] = 0.f;
-        if (i < stat_lim) atomicAdd(stat_prev + i, v);
+        const float v = ((sstat[i] + sstat[2 * BN + i]) + sstat[4 * BN + i]) + sstat[6 * BN + i];
+        if (i < stat_lim) stat_prev[i] = v;
       }
     }
   };
@@ -868,20 +867,22 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
         }
       }
       if (flags & TFC_EP_STATS) {
-        // lanes with equal (lane % UPR) hold partial sums of the same 8 channels: butterfly over them, then the four waves meet in LDS (float
-        // atomics on 2 * BN words), and ONE wave adds the tile's 2 * BN sums to memory as whole 256-byte runs of stats[img][n][2] -- 16 global
-        // atomics per lane at a 64-byte lane stride (the first version) ran 6x slower than the whole convolution
+        // lanes with equal (lane % UPR) hold partial sums of the same 8 channels: butterfly over them (a fixed tree), then each wave stores its sums
+        // into its own LDS slot; wave 0 adds the four slots in wave order one tile later (stat_flush) and writes the tile's 2 * BN sums as whole
+        // 256-byte runs of part[img][tile][n][2]
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
           for (int o = 32; o >= UPR; o >>= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
         }
         if (lane < UPR) {
-          float* sp = sstat + (tcount & 1) * 2 * BN + ps * 2 * BNS;
+          float2* sp = reinterpret_cast<float2*>(sstat + wave * 2 * BN + ps * 2 * BNS) + su * 8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { atomicAdd(&sp[(su * 8 + e) * 2], s1[e]); atomicAdd(&sp[(su * 8 + e) * 2 + 1], s2[e]); }
+          for (int e = 0; e < 8; ++e) sp[e] = make_float2(s1[e], s2[e]);
         }
-        stat_prev = stats + ((size_t)cur.img * d.Nout + cur.nb_blk * BN) * 2;
+        const int tpi = d.tiles_y * d.tiles_x;
+        const int tile_id = (cur.phy * 2 + cur.phx) * tpi + (cur.a0 / TFC_TILE_H) * d.tiles_x + cur.b0 / TFC_TILE_W;
+        stat_prev = stats + (((size_t)cur.img * (tpi * (d.ph_n > 1 ? d.ph_n : 1)) + tile_id) * d.Nout + cur.nb_blk * BN) * 2;
         stat_lim = 2 * (d.Nout - cur.nb_blk * BN);                // floats of this n-block that exist
       }
     }
@@ -2025,36 +2026,36 @@ tfc_wgrad_c8_kernel(const TfcGather d, const bf16_t* __restrict__ dO, const bf16
 // 3 x 3 -- window taps) * (y > 0 ? 1 : slope), rounds to bf16 where the unfused kernel stored it, and writes the dO tile the MFMA loop reads.
 // Reads 266 + 67 + 33 MB, writes 32 KB of slabs per workgroup. Tap weights with the reflect aliases merged are tabulated per tile row / column
 // exactly as in tfc_act_pool2_bwd_kernel, and the arithmetic order is the same, so d_raw -- and with it the weight gradient -- has the same bits.
-// Tiles are dealt out CONTIGUOUSLY (a workgroup stays within one or two images), so the bias-gradient sums leave as 64 atomics per image touched.
+// Tiles are dealt out CONTIGUOUSLY inside ONE image per workgroup (wpi workgroups per image), so the bias-gradient sums leave as one 64-float slot
+// rstats = part[img][workgroup of the image][64], added in a fixed order by tfc_part_reduce_kernel (round 2 used LDS + memory-side float atomics).
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fbw(int k) { return (k == 0 || k == 3) ? 0.125f : 0.375f; }
 __global__ void __launch_bounds__(256, 2)
 tfc_wgrad_c8_fused_kernel(const TfcGather d, const bf16_t* __restrict__ yact, int y_pitch, const bf16_t* __restrict__ dyp, int dyp_pitch, int Ho, int Wo,
-                          const bf16_t* __restrict__ in, float4* __restrict__ slab, float* rstats, float slope, int nsplit) {
+                          const bf16_t* __restrict__ in, float4* __restrict__ slab, float* rstats, float slope, int wpi, int per) {
   constexpr int ROWB = 64;
   constexpr int DO_BYTES = 2 * 128 * ROWB;
   constexpr int HALO_BYTES = (TFC_MAX_HH * TFC_MAX_HW * 16 + 255) & ~255;
   constexpr int WH = 7, WW = 11, WIN_BYTES = WH * WW * 8 * 16;     // pooled-gradient window: 77 pixels x 64 channels
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DO_BYTES + 2 * HALO_BYTES + WIN_BYTES + 24 * 16 + 2 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DO_BYTES + 2 * HALO_BYTES + WIN_BYTES + 24 * 16 + 4 * 64 * 4];
   unsigned char* halo0 = smem + DO_BYTES;
   uint4* win = reinterpret_cast<uint4*>(smem + DO_BYTES + 2 * HALO_BYTES);
   float4* wrow = reinterpret_cast<float4*>(smem + DO_BYTES + 2 * HALO_BYTES + WIN_BYTES);   // [8] tap weights of pooled rows o0-1, o0, o0+1
   float4* wcol = wrow + 8;                                                                  // [16]
-  float* sbias = reinterpret_cast<float*>(wcol + 16);                                       // [64] bias-gradient sums of the current image
+  float* sbias = reinterpret_cast<float*>(wcol + 16);                                       // [4 waves][64] bias-gradient sums of this workgroup
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TfcPlane& pd = d.plane[0];
   const int sp = blockIdx.x;
-  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
-  const int per = (ntiles + nsplit - 1) / nsplit;
-  const int t0 = sp * per, t1 = (t0 + per) < ntiles ? (t0 + per) : ntiles;
+  const int tpi = d.tiles_y * d.tiles_x;                          // tiles per image; this workgroup: tiles [t0, t1) of image sp / wpi
+  const int wimg = sp / wpi, wj = sp - wimg * wpi;
+  const int t0 = wimg * tpi + wj * per, t1 = (wj * per + per) < tpi ? (t0 + per) : (wimg + 1) * tpi;
   f32x16_t acc[2];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[ni][j] = 0.f;
-  if (tid < 64) sbias[tid] = 0.f;
 
   auto decode = [&](int tl, int& img, int& a0, int& b0) {
     int t = tl;
@@ -2128,24 +2129,11 @@ tfc_wgrad_c8_fused_kernel(const TfcGather d, const bf16_t* __restrict__ yact, in
   for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[h2][e] = 0.f;
-  int img_cur = -1;
-  auto flush_bias = [&](int img) {                                // all threads; called between barriers
-    if (!rstats || img < 0) return;
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { atomicAdd(&sbias[h2 * 32 + (tid & 3) * 8 + e], bsum[h2][e]); bsum[h2][e] = 0.f; }
-    __syncthreads();
-    if (tid < 64) { atomicAdd(&rstats[(size_t)img * 64 + tid], sbias[tid]); sbias[tid] = 0.f; }
-    __syncthreads();
-  };
-
   if (t0 < t1) tile_load(t0);
   int cur = 0;
   for (int tl = t0; tl < t1; ++tl) {
     int img, a0, b0;
     decode(tl, img, a0, b0);
-    if (img != img_cur) { flush_bias(img_cur); img_cur = img; }
     // A. window, halo, tap tables of this tile -> LDS; the activation units stay in registers
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const int idx = tid + i * 256; if (idx < WH * WW * 8) win[idx] = vw[i]; }
@@ -2212,8 +2200,21 @@ tfc_wgrad_c8_fused_kernel(const TfcGather d, const bf16_t* __restrict__ yact, in
     }
     cur ^= 1;
   }
-  __syncthreads();
-  flush_bias(img_cur);
+  if (rstats) {
+    // bias-gradient sums of this workgroup, in a fixed order: the lanes that share (lane & 3) hold the same 16 channels -> butterfly over lane bits
+    // 2..5, the four waves meet in four LDS slots, 64 threads add the slots in wave order
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = bsum[h2][e];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (lane < 4) sbias[wave * 64 + h2 * 32 + lane * 8 + e] = v;
+      }
+    __syncthreads();
+    if (tid < 64) rstats[(size_t)sp * 64 + tid] = ((sbias[tid] + sbias[64 + tid]) + sbias[128 + tid]) + sbias[192 + tid];   // part[img][wj][64], sp = img * wpi + wj
+  }
   float4* ps = slab + ((size_t)sp * 4 + wave) * (2 * 4 * 64) + lane;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
@@ -2221,19 +2222,24 @@ tfc_wgrad_c8_fused_kernel(const TfcGather d, const bf16_t* __restrict__ yact, in
     for (int q4 = 0; q4 < 4; ++q4)
       ps[(ni * 4 + q4) * 64] = make_float4(acc[ni][4 * q4], acc[ni][4 * q4 + 1], acc[ni][4 * q4 + 2], acc[ni][4 * q4 + 3]);
 }
-// position = ((ky * 2 + ni) * 4 + q4) * 64 + lane of the 2048 float4 of a workgroup slab; block = 256 positions x one of `nchunk` slab ranges
+// position = ((ky * 2 + ni) * 4 + q4) * 64 + lane of the 2048 float4 of a workgroup slab. A block owns 16 positions; its 16 slab-lanes take the slabs
+// sp = l, l + 16, ... ascending and meet in LDS in lane order: a fixed summation order and ONE owner per accumulator element (no atomics).
 __global__ void __launch_bounds__(256)
-tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int nchunk, int Nn_real, int Cw_real) {
-  const int pos = (blockIdx.x & 7) * 256 + threadIdx.x;
-  const int ch = blockIdx.x >> 3;
-  const int per = (nsplit + nchunk - 1) / nchunk;
-  const int s0 = ch * per, s1 = (s0 + per) < nsplit ? (s0 + per) : nsplit;
+tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int Nn_real, int Cw_real) {
+  __shared__ float4 red[16][16];
+  const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int pos = blockIdx.x * 16 + pl;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-  for (int sp = s0; sp < s1; ++sp) {
+  for (int sp = sl; sp < nsplit; sp += 16) {
     const float4 v = slab[(size_t)sp * 2048 + pos];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
+  red[sl][pl] = s;
+  __syncthreads();
+  if (sl != 0) return;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) { const float4 v = red[i][pl]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   const int lane = pos & 63, q4 = (pos >> 6) & 3, ni = (pos >> 8) & 1, ky = pos >> 9;
   const int col = lane & 31, kx = col >> 3, c = col & 7;
   const int n0 = ni * 32 + 8 * q4 + 4 * (lane >> 5);
@@ -2241,7 +2247,7 @@ tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nspl
   const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    if (n0 + e < Nn_real) atomicAdd(&acc[((size_t)(ky * 4 + kx) * Nn_real + n0 + e) * Cw_real + c], sv[e]);
+    if (n0 + e < Nn_real) acc[((size_t)(ky * 4 + kx) * Nn_real + n0 + e) * Cw_real + c] += sv[e];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2637,40 +2643,57 @@ tfc_wgrad_head_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch,
     for (int q4 = 0; q4 < 4; ++q4)
       ps[(a * 4 + q4) * 64] = make_float4(acc[a][4 * q4], acc[a][4 * q4 + 1], acc[a][4 * q4 + 2], acc[a][4 * q4 + 3]);
 }
-// position = ((w * 9 + a) * 4 + q4) * 64 + lane of the 9216 float4 of a workgroup slab; block = 256 positions x one of `nchunk` slab ranges.
-// row (phase * 8 + oc) of offset a = ir * 3 + ic feeds every filter tap that collapses onto that offset in that phase.
+// position = ((w * 9 + a) * 4 + q4) * 64 + lane of the 9216 float4 of a workgroup slab. Stage 1 sums the slabs position by position (16 positions x 16
+// slab-lanes per block, slab-lanes take sp = l, l + 16, ... ascending and meet in LDS in lane order) and leaves the total IN PLACE in slab 0.
 __global__ void __launch_bounds__(256)
-tfc_wgrad_head_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int nchunk, int Nn_real, int Cw_real) {
-  const int pos = (blockIdx.x % 36) * 256 + threadIdx.x;
-  const int ch = blockIdx.x / 36;
-  const int per = (nsplit + nchunk - 1) / nchunk;
-  const int s0 = ch * per, s1 = (s0 + per) < nsplit ? (s0 + per) : nsplit;
+tfc_wgrad_head_reduce_kernel(float4* __restrict__ slab, int nsplit) {
+  __shared__ float4 red[16][16];
+  const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int pos = blockIdx.x * 16 + pl;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-  for (int sp = s0; sp < s1; ++sp) {
+  for (int sp = sl; sp < nsplit; sp += 16) {
     const float4 v = slab[(size_t)sp * 9216 + pos];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  const int lane = pos & 63, q4 = (pos >> 6) & 3, a = (pos >> 8) % 9, w = pos / 2304;
-  const int c = w * 32 + (lane & 31);
-  const int row0 = 8 * q4 + 4 * (lane >> 5);
-  const int ph = row0 >> 3, oc0 = row0 & 7;                       // the four rows of a float4 share their phase (row0 % 4 == 0)
-  if (c >= Cw_real) return;
-  const int wpy = ph >> 1, wpx = ph & 1, ir = a / 3, ic = a % 3;
-  int mask = 0;
-  if (ir < 2 + wpy && ic < 2 + wpx)
-    for (int ky = 0; ky < 4; ++ky)
-      for (int kx = 0; kx < 4; ++kx) {
+  red[sl][pl] = s;
+  __syncthreads();
+  if (sl != 0) return;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) { const float4 v = red[i][pl]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  slab[pos] = s;
+}
+// Stage 2 (replaces tfc_wgrad_finish_kernel for the head): one thread per (oc, c) GATHERS its 16 filter taps -- row (phase * 8 + oc) of source offset
+// a = ir * 3 + ic feeds every filter tap that collapses onto that offset in that phase, so a tap is the sum of four rows (one per phase, phase order);
+// round 2 scattered them with float atomics.
+__global__ void __launch_bounds__(256)
+tfc_wgrad_head_finish_kernel(const float4* __restrict__ S, float* __restrict__ grad, int Nn_real, int Cw_real, long long sn, long long sc, int accumulate) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Nn_real * Cw_real) return;
+  const int c = idx % Cw_real, oc = idx / Cw_real;
+  const int w = c >> 5, lane = (oc >> 2) * 32 + (c & 31), e = oc & 3;
+  float v[16];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      float t = 0.f;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const int wpy = ph >> 1, wpx = ph & 1;
         const int sy = wpy ? (ky == 0 ? 0 : (ky == 3 ? 2 : 1)) : (ky >> 1);   // source row offset + 1 of filter row ky in this phase
         const int sx = wpx ? (kx == 0 ? 0 : (kx == 3 ? 2 : 1)) : (kx >> 1);
-        if (sy == ir && sx == ic) mask |= 1 << (ky * 4 + kx);
+        const float4 q = S[((size_t)(w * 9 + sy * 3 + sx) * 4 + ph) * 64 + lane];
+        t += e == 0 ? q.x : (e == 1 ? q.y : (e == 2 ? q.z : q.w));
       }
-  const float sv[4] = {s.x, s.y, s.z, s.w};
-  for (int m = mask; m; m &= m - 1) {
-    const int slot = __ffs(m) - 1;
+      v[ky * 4 + kx] = t;
+    }
+  float4* g = reinterpret_cast<float4*>(grad + (long long)oc * sn + (long long)c * sc);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (oc0 + e < Nn_real) atomicAdd(&acc[((size_t)slot * Nn_real + oc0 + e) * Cw_real + c], sv[e]);
+  for (int q4 = 0; q4 < 4; ++q4) {
+    float4 o = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+    if (accumulate) { const float4 p = g[q4]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+    g[q4] = o;
   }
 }
 
@@ -2898,7 +2921,7 @@ static int match_pattern(const TfcGather& d, int es) {
 
 template <typename T, int MT, int NT, int WM, int WN, int PAT>
 static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                   float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
+                                   float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   constexpr int ES = sizeof(T);
   const int NB32 = tfc_nb32_padded(d.Nout);
   const int per_blk = NT * WN;
@@ -2914,8 +2937,14 @@ static hipError_t launch_igemm_pat(const TfcGather& d, const void* in, const voi
   }
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1);
   const long long phase_wbytes = (long long)tfc_packed_bytes(d, ES);
+  // InstanceNorm sums: every (tile, M-wave) stores its partial into part_ws[img][tile * WM + wm][Nout][2]; a fixed-order pass adds them to stats
+  const int nparts = d.tiles_y * d.tiles_x * WM * (d.ph_n > 1 ? d.ph_n : 1);
+  if (flags & TFC_EP_STATS) {
+    if (!part_ws || (long long)d.nimg * nparts * d.Nout * 2 > (long long)TFC_PART_WS_FLOATS) return hipErrorInvalidValue;
+  }
   TFC_LAUNCH((tfc_igemm_kernel<T, MT, NT, WM, WN, PAT>), dim3(ntiles * nblkN), dim3(256), lds, st, d,
-                     (const T*)in, (const uint4*)wp, (T*)out, bias, stats, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes);
+                     (const T*)in, (const uint4*)wp, (T*)out, bias, part_ws, out_nchw, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes);
+  if (flags & TFC_EP_STATS) return tfc_launch_part_reduce(part_ws, stats, d.nimg, nparts, 2 * d.Nout, st);
   return hipGetLastError();
 }
 
@@ -2930,7 +2959,7 @@ static int tfc_num_cus() {
 }
 template <int MT, int NT, int WM, int WN, int PAT>
 static hipError_t launch_igemm2_pat(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                    float* stats, float* dbg, const float* oscale, int flags, hipStream_t st) {
+                                    float* stats, float* part_ws, float* dbg, const float* oscale, int flags, hipStream_t st) {
   const int NB32 = tfc_nb32_padded(d.Nout);
   const int per_blk = NT * WN;
   const int nblkN = (tfc_nb32(d.Nout) + per_blk - 1) / per_blk;
@@ -2941,7 +2970,13 @@ static hipError_t launch_igemm2_pat(const TfcGather& d, const void* in, const vo
   constexpr int BNS = BN > 128 ? 32 * WN : BN;                    // channels of one staged epilogue pass
   constexpr int STG = 128 * (BNS * 2 + 16);
   // 256-channel tile: the staged tile overlays a consumed halo buffer (see the kernel's LDS map)
-  const int lds = (BN > 128 ? 2 * buf_bytes + (STG > buf_bytes ? STG - buf_bytes : 0) : 2 * buf_bytes + STG) + 4 * BN * 4 + nblkN * BN * 4;   // halo x 2 | staged tile | statistics x 2 | bias table
+  // halo x 2 | staged tile | per-wave statistics slots (EP_STATS) | bias table (EP_BIAS)
+  const int lds = (BN > 128 ? 2 * buf_bytes + (STG > buf_bytes ? STG - buf_bytes : 0) : 2 * buf_bytes + STG) + ((flags & TFC_EP_STATS) ? 8 * BN * 4 : 0) +
+                  ((flags & TFC_EP_BIAS) ? nblkN * BN * 4 : 0);
+  const int nparts = d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1);   // InstanceNorm partial slots per image: part_ws[img][phase][tile][Nout][2]
+  if (flags & TFC_EP_STATS) {
+    if (!part_ws || (long long)d.nimg * nparts * d.Nout * 2 > (long long)TFC_PART_WS_FLOATS) return hipErrorInvalidValue;
+  }
   const int nwork = d.nimg * d.tiles_y * d.tiles_x * (d.ph_n > 1 ? d.ph_n : 1) * nblkN;
   // resident workgroups per CU of THIS instantiation (2 for the 128-channel tile: 77 KB of LDS, ~195 VGPRs; 3 for the narrower tiles); a persistent
   // grid never depends on co-residency for correctness (no inter-workgroup waits), so the occupancy query only sizes the grid
@@ -2955,36 +2990,37 @@ static hipError_t launch_igemm2_pat(const TfcGather& d, const void* in, const vo
   const int cap = occ_cache * tfc_num_cus();
   const long long phase_wbytes = (long long)tfc_packed_bytes(d, 2);
   TFC_LAUNCH((tfc_igemm2_kernel<MT, NT, WM, WN, PAT>), dim3(nwork < cap ? nwork : cap), dim3(256), lds, st, d, (const bf16_t*)in, (const uint4*)wp,
-             (bf16_t*)out, bias, stats, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork);
+             (bf16_t*)out, bias, part_ws, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork);
+  if (flags & TFC_EP_STATS) return tfc_launch_part_reduce(part_ws, stats, d.nimg, nparts, 2 * d.Nout, st);
   return hipGetLastError();
 }
 template <int MT, int NT, int WM, int WN>
 static hipError_t launch_igemm2_cfg(int pat, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                    float* stats, float* dbg, const float* oscale, int flags, hipStream_t st) {
+                                    float* stats, float* part_ws, float* dbg, const float* oscale, int flags, hipStream_t st) {
   switch (pat) {
-    case 1: return launch_igemm2_pat<MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
-    case 2: return launch_igemm2_pat<MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
-    case 3: return launch_igemm2_pat<MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
-    default: return launch_igemm2_pat<MT, NT, WM, WN, 6>(d, in, wp, out, bias, stats, dbg, oscale, flags, st);
+    case 1: return launch_igemm2_pat<MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, part_ws, dbg, oscale, flags, st);
+    case 2: return launch_igemm2_pat<MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, part_ws, dbg, oscale, flags, st);
+    case 3: return launch_igemm2_pat<MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, part_ws, dbg, oscale, flags, st);
+    default: return launch_igemm2_pat<MT, NT, WM, WN, 6>(d, in, wp, out, bias, stats, part_ws, dbg, oscale, flags, st);
   }
 }
 
 template <typename T, int MT, int NT, int WM, int WN>
 static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                   float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
+                                   float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     // bf16, compile-time tap pattern, whole 16-byte output units, NHWC output: the persistent kernel (test hook: config | 16 = one tile per workgroup)
     const int pat = match_pattern(d, 2);
     static const bool legacy_env = [] { const char* e = getenv("TFC_LEGACY_IGEMM"); return e && atoi(e) != 0; }();   // A/B knob for profiling
     if (pat != 0 && d.Nout % 8 == 0 && !(flags & TFC_EP_TANH_NCHW) && !(g_tfc_force_cfg >= 16) && !legacy_env)
-      return launch_igemm2_cfg<MT, NT, WM, WN>(pat, d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+      return launch_igemm2_cfg<MT, NT, WM, WN>(pat, d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
   }
   switch (match_pattern(d, sizeof(T))) {
-    case 1: return launch_igemm_pat<T, MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-    case 2: return launch_igemm_pat<T, MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-    case 3: return launch_igemm_pat<T, MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-    case 6: return launch_igemm_pat<T, MT, NT, WM, WN, 6>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-    default: return launch_igemm_pat<T, MT, NT, WM, WN, 0>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    case 1: return launch_igemm_pat<T, MT, NT, WM, WN, 1>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+    case 2: return launch_igemm_pat<T, MT, NT, WM, WN, 2>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+    case 3: return launch_igemm_pat<T, MT, NT, WM, WN, 3>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+    case 6: return launch_igemm_pat<T, MT, NT, WM, WN, 6>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+    default: return launch_igemm_pat<T, MT, NT, WM, WN, 0>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
   }
 }
 
@@ -2996,7 +3032,7 @@ thread_local long long g_tfc_launch_count = 0;
 
 template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                                 float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
+                                 float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   const int nb = tfc_nb32(d.Nout);
   const int fcfg = g_tfc_force_cfg < 0 ? -1 : (g_tfc_force_cfg & 15);     // bit 4 of the test hook selects the one-tile-per-workgroup kernel
   if constexpr (sizeof(T) == 2) {
@@ -3020,13 +3056,13 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
   }
 #ifdef TFC_PROBE_W64
   if constexpr (sizeof(T) == 2) {
-    if (fcfg == 4 && nb >= 8) return launch_igemm2_cfg<4, 2, 1, 4>(match_pattern(d, 2), d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+    if (fcfg == 4 && nb >= 8) return launch_igemm2_cfg<4, 2, 1, 4>(match_pattern(d, 2), d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
   }
 #endif
-  if (fcfg == 3 && nb >= 4) return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if (fcfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if ((fcfg == 0 || fcfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if (fcfg >= 0 && fcfg != 15) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (fcfg == 3 && nb >= 4) return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+  if (fcfg == 0 && nb >= 4) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+  if ((fcfg == 0 || fcfg == 1) && nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+  if (fcfg >= 0 && fcfg != 15) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
   const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
   const int target = 512;
   if constexpr (sizeof(T) == 2) {
@@ -3038,18 +3074,18 @@ static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void*
     static const bool old_rule = [] { const char* e = getenv("TFC_TILE_RULE_OLD"); return e && atoi(e) != 0; }();   // A/B knob for profiling
     const int w128 = ntiles * (d.ph_n > 1 ? d.ph_n : 1) * ((nb + 3) / 4);
     if (!old_rule && nb >= 4 && d.Cin_pad >= 64 && w128 >= tfc_num_cus() && (w128 < 2048 || d.Cin_pad >= 128))   // (128 -> 256 at 64 x 64: 130 -> 124 us; 64 -> 128 at 128 x 128 stays on <2,2,2,2>: 132 vs 157)   // (also 1-3 % ahead of <2,2,2,2> at 32 x 32 256->512; the two are equal beyond)
-      return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+      return launch_igemm_cfg<T, 4, 1, 1, 4>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
   }
-  if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if (nb >= 2 && (ntiles * ((nb + 1) / 2) >= target || nb < 4)) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if (nb >= 4 && ntiles * nb < target / 2) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  if (nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
-  return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+  if (nb >= 4 && ntiles * ((nb + 3) / 4) >= target) return launch_igemm_cfg<T, 2, 2, 2, 2>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+  if (nb >= 2 && (ntiles * ((nb + 1) / 2) >= target || nb < 4)) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+  if (nb >= 4 && ntiles * nb < target / 2) return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+  if (nb >= 2) return launch_igemm_cfg<T, 2, 1, 2, 2>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
+  return launch_igemm_cfg<T, 1, 1, 4, 1>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
 }
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
-                            float* stats, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
-  return dt == TFC_DT_BF16 ? launch_igemm_t<bf16_t>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st)
-                           : launch_igemm_t<float>(d, in, wp, out, bias, stats, out_nchw, oscale, flags, st);
+                            float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
+  return dt == TFC_DT_BF16 ? launch_igemm_t<bf16_t>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st)
+                           : launch_igemm_t<float>(d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
 }
 
 // fin (nullable): torch-layout destination of the gradient. When the launch can reduce its slabs straight into it (tfc_wgrad_reduce_fin_kernel),
@@ -3107,8 +3143,7 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
         d.plane[0].hh <= TFC_MAX_HH && d.plane[0].hw <= TFC_MAX_HW && (g_tfc_force_cfg < 0 || (g_tfc_force_cfg & 15) == 15)) {
       const int ns = ntiles < 512 ? ntiles : 512;                 // 2 workgroups per CU, 32 KB of slab each
       TFC_LAUNCH(tfc_wgrad_c8_kernel, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)dO, (const bf16_t*)in, slab, Nn_pad, ns);
-      const int nchunk = ns >= 16 ? 16 : 1;
-      TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(8 * nchunk), dim3(256), 0, st, slab, dwacc, ns, nchunk, Nn_real, Cw_real);
+      TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(128), dim3(256), 0, st, slab, dwacc, ns, Nn_real, Cw_real);
       return hipGetLastError();
     }
   }
@@ -3131,13 +3166,20 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
 }
 // fused first-block backward (tfc_wgrad_c8_fused_kernel): d = the TFC_OP_CONV pass-2 descriptor of the layer (8 padded input channels, 64 outputs)
 hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
-                                      void* slab, float* dwacc, float* rstats, float slope, int Nn_real, int Cw_real, hipStream_t st) {
-  const int ntiles = d.nimg * d.tiles_y * d.tiles_x;
-  const int ns = ntiles < 512 ? ntiles : 512;
+                                      void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real, hipStream_t st) {
+  // wpi workgroups per image, each with `per` consecutive tiles of that image: about 512 workgroups in all (2 per CU), at most 2048 (32 KB of slab each)
+  const int tpi = d.tiles_y * d.tiles_x;
+  int wpi = 512 / d.nimg;
+  if (wpi < 1) wpi = 1;
+  if (wpi > tpi) wpi = tpi;
+  const int per = (tpi + wpi - 1) / wpi;
+  wpi = (tpi + per - 1) / per;
+  const int ns = d.nimg * wpi;
+  if (ns > 2048 || (rstats && (!part_ws || (long long)ns * 64 > (long long)TFC_PART_WS_FLOATS))) return hipErrorInvalidValue;
   TFC_LAUNCH(tfc_wgrad_c8_fused_kernel, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)yact, y_pitch, (const bf16_t*)dyp, dyp_pitch, Ho, Wo,
-             (const bf16_t*)in, (float4*)slab, rstats, slope, ns);
-  const int nchunk = ns >= 16 ? 16 : 1;
-  TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(8 * nchunk), dim3(256), 0, st, (const float4*)slab, dwacc, ns, nchunk, Nn_real, Cw_real);
+             (const bf16_t*)in, (float4*)slab, rstats ? part_ws : nullptr, slope, wpi, per);
+  TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(128), dim3(256), 0, st, (const float4*)slab, dwacc, ns, Nn_real, Cw_real);
+  if (rstats) return tfc_launch_part_reduce(part_ws, rstats, d.nimg, wpi, 64, st);   // rstats[img][64] += the image's workgroup slots, in order
   return hipGetLastError();
 }
 // transposed convolution / upsample conv, bf16: all four phases in one launch; false = not applicable (caller falls back to per-phase launches)
@@ -3164,9 +3206,12 @@ bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW,
     int ns = (int)(budget / wg_bytes);
     if (ns > 512) ns = 512;
     if (ns > ntiles) ns = ntiles;
+    if (!fin || !fin->grad || fin->sn % 4 != 0 || fin->sc % 4 != 0) return false;   // the head's own finish pass writes the torch-layout gradient
     TFC_LAUNCH(tfc_wgrad_head_kernel, dim3(ns), dim3(256), 0, st, (const bf16_t*)x, IH, IW, x_pitch, (const bf16_t*)dy, dy_pitch, N, (float4*)slab, ns);
-    const int nchunk = ns >= 64 ? 8 : 1;
-    TFC_LAUNCH(tfc_wgrad_head_reduce_kernel, dim3(36 * nchunk), dim3(256), 0, st, (const float4*)slab, dwacc, ns, nchunk, Cout, Cin);
+    TFC_LAUNCH(tfc_wgrad_head_reduce_kernel, dim3(576), dim3(256), 0, st, (float4*)slab, ns);
+    TFC_LAUNCH(tfc_wgrad_head_finish_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, st, (const float4*)slab, fin->grad, Cout, Cin, fin->sn, fin->sc,
+               fin->accumulate);
+    fin->done = true;
     *err = hipGetLastError();
     return true;
   }
@@ -3194,7 +3239,7 @@ bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW,
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad,
                             int Nn_real, int Cw_real, hipStream_t st, TfcWgradFin* fin) {
   return dt == TFC_DT_BF16 ? launch_wgrad_t<bf16_t>(d, dO, in, dwacc, (float4*)slab, Nn_pad, Nn_real, Cw_real, st, fin)
-                           : launch_wgrad_t<float>(d, dO, in, dwacc, nullptr, Nn_pad, Nn_real, Cw_real, st, nullptr);
+                           : launch_wgrad_t<float>(d, dO, in, dwacc, (float4*)slab, Nn_pad, Nn_real, Cw_real, st, nullptr);   // fp32 too: slabs, not atomics (deterministic)
 }
 hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long long sn, long long sc,
                                    int accumulate, hipStream_t st) {

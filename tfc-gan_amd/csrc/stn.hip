@@ -69,7 +69,8 @@ tfc_affine_warp_fwd_kernel(const float* __restrict__ src, const float* __restric
   }
 }
 
-// gout: d loss / d out.  dtheta[N][6] += ...;  dsrc (nullable) [N][C][H][W] += ... (caller zeroes both)
+// gout: d loss / d out.  dtheta = part[n][blockIdx.x][6] (one slot per workgroup, added in a fixed order by tfc_part_reduce_kernel);
+// dsrc (nullable) [N][C][H][W] += ... (a scatter through float atomics; the launcher zeroes it)
 __global__ void __launch_bounds__(256)
 tfc_affine_warp_bwd_kernel(const float* __restrict__ src, const float* __restrict__ theta, const float* __restrict__ gout, float* dtheta,
                            float* dsrc, int N, int C, int H, int W) {
@@ -113,7 +114,8 @@ tfc_affine_warp_bwd_kernel(const float* __restrict__ src, const float* __restric
   if ((threadIdx.x & 63) == 0)
     for (int k = 0; k < 6; ++k) red[threadIdx.x >> 6][k] = g6[k];
   __syncthreads();
-  if (threadIdx.x < 6) atomicAdd(&dtheta[n * 6 + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 6)
+    dtheta[((size_t)n * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // morphological gradient with the 3 x 3 cross {(0,0), (-1,0), (1,0), (0,-1), (0,1)}: out = max - min over the in-image neighbours.
@@ -138,15 +140,26 @@ tfc_morph_grad_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, 
   out[idx] = mx - mn;
   if (arg) arg[idx] = (unsigned char)(amx | (amn << 4));
 }
+// backward as a GATHER (deterministic; round 2 scattered with float atomics): pixel p collects +g[q] from every in-image neighbour q (and itself)
+// whose arg-max code points at p, and -g[q] where the arg-min code does; code k <-> offset {0, -W, +W, -1, +1}[k], so q = p - offset[k]
 __global__ void __launch_bounds__(256)
-tfc_morph_grad_bwd_kernel(const float* __restrict__ gout, const unsigned char* __restrict__ arg, float* dx, long long planes, int H, int W) {
+tfc_morph_grad_bwd_kernel(const float* __restrict__ gout, const unsigned char* __restrict__ arg, float* __restrict__ dx, long long planes, int H, int W) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= planes * H * W) return;
+  const int j = (int)(idx % W), i = (int)((idx / W) % H);
   const int off[5] = {0, -W, W, -1, 1};
-  const float g = gout[idx];
-  const int a = arg[idx];
-  atomicAdd(&dx[idx + off[a & 15]], g);
-  atomicAdd(&dx[idx + off[a >> 4]], -g);
+  const bool ok[5] = {true, i + 1 < H, i >= 1, j + 1 < W, j >= 1};   // q = p - off[k] inside the image
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (!ok[k]) continue;
+    const long long q = idx - off[k];
+    const int a = arg[q];
+    const float g = gout[q];
+    if ((a & 15) == k) s += g;
+    if ((a >> 4) == k) s -= g;
+  }
+  dx[idx] = s;
 }
 
 // triplet margin loss over rows of width W (p = 2, eps added to the difference like F.pairwise_distance), mean over rows, with d / d anchor.
@@ -187,13 +200,15 @@ hipError_t tfc_launch_affine_warp_fwd(const float* src, const float* theta, floa
   hipLaunchKernelGGL(tfc_affine_warp_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, theta, out, N, C, H, W);
   return hipGetLastError();
 }
-hipError_t tfc_launch_affine_warp_bwd(const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, int N, int C, int H, int W,
-                                      hipStream_t st) {
+hipError_t tfc_launch_affine_warp_bwd(const float* src, const float* theta, const float* gout, float* dtheta, float* dsrc, float* part_ws, int N, int C,
+                                      int H, int W, hipStream_t st) {
+  const unsigned nbx = (unsigned)(((long long)H * W + 255) / 256);
+  if (!part_ws || (long long)nbx * N * 6 > (long long)TFC_PART_WS_FLOATS) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(dtheta, 0, sizeof(float) * 6 * N, st);
   if (e != hipSuccess) return e;
   if (dsrc && (e = hipMemsetAsync(dsrc, 0, sizeof(float) * (size_t)N * C * H * W, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(tfc_affine_warp_bwd_kernel, dim3((unsigned)(((long long)H * W + 255) / 256), N), dim3(256), 0, st, src, theta, gout, dtheta, dsrc, N, C, H, W);
-  return hipGetLastError();
+  hipLaunchKernelGGL(tfc_affine_warp_bwd_kernel, dim3(nbx, N), dim3(256), 0, st, src, theta, gout, part_ws, dsrc, N, C, H, W);
+  return tfc_launch_part_reduce(part_ws, dtheta, N, (int)nbx, 6, st);
 }
 hipError_t tfc_launch_morph_grad_fwd(const float* x, float* out, unsigned char* arg, long long planes, int H, int W, hipStream_t st) {
   const long long tot = planes * H * W;
@@ -202,8 +217,6 @@ hipError_t tfc_launch_morph_grad_fwd(const float* x, float* out, unsigned char* 
 }
 hipError_t tfc_launch_morph_grad_bwd(const float* gout, const unsigned char* arg, float* dx, long long planes, int H, int W, hipStream_t st) {
   const long long tot = planes * H * W;
-  hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)tot, st);
-  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tfc_morph_grad_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gout, arg, dx, planes, H, W);
   return hipGetLastError();
 }

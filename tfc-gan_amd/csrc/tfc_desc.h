@@ -24,6 +24,8 @@
 #define TFC_MAX_TAPS 16
 #define TFC_MAX_PLANES 4
 #define TFC_WPAD 16           // slack k-substeps at the end of a packed weight stream (prefetch distance headroom)
+#define TFC_PART_WS_FLOATS (8 << 20)   // floats of the per-stream partial-sum scratch every reducing entry point takes (32 MiB; include/tfc_gan.h)
+#define TFC_SN_BWD_PARTS 128           // workgroup partials (doubles) of the spectral-norm backward's dot product
 
 #define TFC_DT_BF16 0
 #define TFC_DT_F32 1
@@ -86,6 +88,9 @@ struct ActParams {
 extern thread_local int g_tfc_force_cfg;          // test hook (tfc_debug_set_igemm_config): -1 = heuristic tile choice
 extern thread_local long long g_tfc_launch_count; // kernel launches issued by the conv-class launchers on this thread (profiling join key)
 #define TFC_LAUNCH(...) do { ++g_tfc_launch_count; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+// fixed-order sum of per-workgroup partials (elementwise.hip): out[g][j] += sum_p part[(g * nparts + p) * L + j]
+hipError_t tfc_launch_part_reduce(const float* part, float* out, int G, int nparts, int L, hipStream_t st);
 
 // torch-layout destination of a weight gradient, handed to the wgrad launchers: when a launch can reduce its split-K slabs straight into it
 // (tfc_wgrad_reduce_fin_kernel) it sets `done` and the caller skips the separate finish pass

@@ -138,6 +138,20 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# Partial-sum scratch of the reducing entry points (include/tfc_gan.h, "DETERMINISM"): sums that cross workgroups leave each workgroup as a partial
+# in a fixed slot of this buffer and are added in a fixed order behind the kernel -- no float atomics anywhere on the training path. One buffer per
+# (device, stream): launches on one stream are ordered, and a kernel's partials are consumed by the reduction queued right behind it.
+_PART_WS = {}
+
+
+def part_ws(device):
+    key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _PART_WS.get(key)
+    if ws is None:
+        ws = _PART_WS[key] = torch.empty(lib().tfc_part_ws_floats(), dtype=torch.float32, device=device)
+    return ctypes.c_void_p(ws.data_ptr())
+
+
 OUT_HW = {OP_CONV: lambda h: h - 1, OP_PADCONV: lambda h: h, OP_CONVT: lambda h: 2 * h, OP_UPCONV: lambda h: 2 * h, OP_CONV3: lambda h: h}
 
 
@@ -191,8 +205,8 @@ def conv_fwd(dt, op, x: View, Cin, Cout, packed, y: View = None, bias=None, stat
     if out_nchw is not None:
         flags |= EP_TANH_NCHW
     check(lib().tfc_conv_fwd(stream_ptr(), dt, op, x.ptr, x.pitch, x.N, x.H, x.W, Cin, Cout, _p(packed),
-                             None if y is None else y.ptr, 0 if y is None else y.pitch, _p(bias), _p(stats), _p(out_nchw), _p(oscale), flags),
-          "tfc_conv_fwd")
+                             None if y is None else y.ptr, 0 if y is None else y.pitch, _p(bias), _p(stats), _p(out_nchw), _p(oscale), flags,
+                             part_ws(x.t.device) if stats is not None else None), "tfc_conv_fwd")
 
 
 def first_block_bwd_supported(dt, Cin, Cout):
@@ -209,7 +223,8 @@ def first_block_bwd_wgrad(dt, x: View, y: View, dy_pooled: View, Cin, Cout, dw, 
         ws = torch.zeros(max(nbytes, nbig), dtype=torch.uint8, device=x.t.device)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
     check(lib().tfc_first_block_bwd_wgrad(stream_ptr(), dt, x.ptr, x.pitch, y.ptr, y.pitch, dy_pooled.ptr, dy_pooled.pitch, x.N, x.H, x.W, Cin, Cout, slope,
-                                          _p(ws), _p(dw), 1 if accumulate else 0, _p(bias_sums)), "tfc_first_block_bwd_wgrad")
+                                          _p(ws), _p(dw), 1 if accumulate else 0, _p(bias_sums), part_ws(x.t.device) if bias_sums is not None else None),
+          "tfc_first_block_bwd_wgrad")
     return ws
 
 
@@ -256,13 +271,14 @@ def conv_wgrad(dt, op, x: View, dy: View, Cin, Cout, dw, accumulate=False, ws=No
 # ---- fused norm / activation / blur-pool ----------------------------------------------------------------------
 def act_fwd(dt, x: View, y: View, stats=None, slope=0.2, pool=0, drop_p=0.0, seed=0, stats_out=None):
     check(lib().tfc_act_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, x.C, _p(stats), 0 if stats is None else 1, slope, pool,
-                            drop_p, seed & 0xFFFFFFFF, y.ptr, y.pitch, _p(stats_out)), "tfc_act_fwd")
+                            drop_p, seed & 0xFFFFFFFF, y.ptr, y.pitch, _p(stats_out), part_ws(x.t.device) if stats_out is not None else None), "tfc_act_fwd")
 
 
 def act_bwd(dt, mode, dy: View, x: View, N, H, W, C, dx: View = None, stats=None, slope=0.2, pool=0, drop_p=0.0, seed=0, rstats=None):
     check(lib().tfc_act_bwd(stream_ptr(), dt, mode, dy.ptr, dy.pitch, None if x is None else x.ptr, 0 if x is None else x.pitch,
                             N, H, W, C, _p(stats), 0 if stats is None else 1, slope, pool, drop_p, seed & 0xFFFFFFFF, _p(rstats),
-                            None if dx is None else dx.ptr, 0 if dx is None else dx.pitch), "tfc_act_bwd")
+                            None if dx is None else dx.ptr, 0 if dx is None else dx.pitch, part_ws(dy.t.device) if rstats is not None else None),
+          "tfc_act_bwd")
 
 
 def dropout_mask(n, drop_p, seed, device):
@@ -297,13 +313,14 @@ def unpack_nchw(dt, v: View, C, out=None, alpha=1.0, beta=0.0, c0=0):
 def tanh_bwd_pack(dt, g, y, dbias=None):
     N, C, H, W = g.shape
     out = new_act(N, H, W, 8, dt, g.device)
-    check(lib().tfc_tanh_bwd_pack(stream_ptr(), dt, _p(g), _p(y), out.ptr, _p(dbias), N, C, H, W), "tfc_tanh_bwd_pack")
+    check(lib().tfc_tanh_bwd_pack(stream_ptr(), dt, _p(g), _p(y), out.ptr, _p(dbias), N, C, H, W, part_ws(g.device) if dbias is not None else None),
+          "tfc_tanh_bwd_pack")
     return out
 
 
 def colsum(dt, v: View, out):
     rows = v.N * v.H * v.W
-    check(lib().tfc_colsum(stream_ptr(), dt, v.ptr, rows, v.pitch, v.C, _p(out)), "tfc_colsum")
+    check(lib().tfc_colsum(stream_ptr(), dt, v.ptr, rows, v.pitch, v.C, _p(out), part_ws(v.t.device) if rows >= 4096 else None), "tfc_colsum")
 
 
 def cast_from_f32(dt, x):
@@ -327,8 +344,9 @@ def axpby(out, x, y, a, b):
 def spectral_norm_step(W, u, v, sigma2, power_iter=True, ws=None):
     R = W.shape[0]
     K = W.numel() // R
-    if ws is None:
-        ws = torch.empty(R + K, dtype=torch.float32, device=W.device)
+    need = lib().tfc_spectral_norm_batched_ws_floats(1, (ctypes.c_int * 1)(R), (ctypes.c_int * 1)(K))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=W.device)
     check(lib().tfc_spectral_norm_step(stream_ptr(), _p(W), _p(u), _p(v), _p(sigma2), _p(ws), R, K, 1 if power_iter else 0),
           "tfc_spectral_norm_step")
 
@@ -353,7 +371,7 @@ def spectral_norm_step_batched(Ws, us, vs, sigma2s, power_iter=True, u_snaps=Non
 def spectral_norm_bwd(G, W, u, v, sigma2, gout, accumulate=False):
     R = W.shape[0]
     K = W.numel() // R
-    ws = torch.empty(1, dtype=torch.float32, device=W.device)
+    ws = torch.empty(256, dtype=torch.float32, device=W.device)    # per-workgroup partials of <G, W> (doubles), added in a fixed order
     check(lib().tfc_spectral_norm_bwd(stream_ptr(), _p(G), _p(W), _p(u), _p(v), _p(sigma2), _p(ws), _p(gout), R, K,
                                       1 if accumulate else 0), "tfc_spectral_norm_bwd")
 

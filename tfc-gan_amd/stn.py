@@ -44,7 +44,8 @@ class _AffineWarpFn(torch.autograd.Function):
         g = _c(g)
         dth = torch.empty((N, 6), dtype=torch.float32, device=s.device)
         dsrc = torch.empty_like(s) if ctx.need_src else None
-        check(ops.lib().tfc_affine_warp_bwd(ops.stream_ptr(), ops._p(s), ops._p(th), ops._p(g), ops._p(dth), ops._p(dsrc), N, C, H, W), "tfc_affine_warp_bwd")
+        check(ops.lib().tfc_affine_warp_bwd(ops.stream_ptr(), ops._p(s), ops._p(th), ops._p(g), ops._p(dth), ops._p(dsrc), N, C, H, W, ops.part_ws(s.device)),
+              "tfc_affine_warp_bwd")
         return dsrc, dth.reshape(ctx.theta_shape)
 
 
