@@ -2,7 +2,8 @@
 """Benchmark of the PATCH-16 training hot path (BASELINE.json metric) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...        (launches its own N ranks: a child `torch.distributed.run`, rank 0's JSON line relayed, non-zero exit if any rank fails)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   (the driver's form)
 
 One process per GPU; each rank trains on its own 32 synthetic 256x256 thermal/visible pairs already resident in HBM
 (weak scaling), gradients are all-reduced over RCCL.  A "step" = the full generator step + discriminator step of
@@ -108,6 +109,21 @@ def generator_l1(dev):
     return out
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without an outer launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (this parent has imported
+    nothing that touches the GPU and never execs), let the child's stdout / stderr through (rank 0 prints the one JSON line) and exit with its code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,15 +140,18 @@ def main():
                          "whole-image FFT loss instead of the 16 patch FFTs)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import tfc_gan_amd as T
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:               # no outer launcher: become one (before anything initialises the GPU)
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
+
+    import torch
+    import torch.distributed as dist
+    import tfc_gan_amd as T
+    from tfc_gan_amd import parallel
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     if os.environ.get("TFC_BENCH_BACKEND", "nccl") != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)   # rehearsal: more ranks than cards
@@ -180,6 +199,7 @@ def main():
     # The roofline object is measured live, inside the timed region, with hipEvent pairs around the MFMA kernel launches on the launch
     # stream. An event pair costs ~2.3 us of stream time (A/B in scripts/ab_prof.py: 0.45 ms per fully instrumented step, 3.5 %), so
     # every PROF_EVERY-th timed step is instrumented, not all of them: `value` then carries < 1 % of instrumentation overhead.
+    parallel.exposed_wait_begin()                          # hipEvent pairs around the waits of BucketReducer.finish(): `exposed_allreduce_ms`
     t0 = time.perf_counter()
     # The product runs its weight gradients on a second stream beside the input-gradient chain (nets.py). A launch that shares the chip with another
     # kernel has no duration of its own, so the INSTRUMENTED steps (and only they) run everything in line on one stream: the roofline object then
@@ -210,10 +230,11 @@ def main():
     dom_ms, dom_flop = sum(r["ms"] for r in dom), sum(r["flop"] for r in dom)
     dom_launches = len(dom)                               # one launch per call: the four sub-pixel phases of a transposed convolution fold into one grid
     loss_g, loss_d = float(out["loss_G"]), float(out["loss_D"])
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    exposed_ms = parallel.exposed_wait_collect() / args.steps    # stream time spent waiting for gradient buckets, per step (0 at one rank)
+    tmax = torch.tensor([elapsed, exposed_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed, exposed_ms = float(tmax[0].item()), float(tmax[1].item())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -249,6 +270,10 @@ def main():
                          "fused_first_block_backward": {"kernel": "tfc_wgrad_c8_fused_kernel (VALU-bound transposed blur + first-layer weight gradient)",
                                                         "calls": fb_n, "avg_call_ms": fb_ms / max(fb_n, 1), "share_of_step_time": (fb_ms / 1e3 / nprof) / step_s}},
             "whole_step_tflops": T.TrainStep.STEP_GFLOP * value / 1e3,
+            # stream time between "all buckets issued" and "all buckets arrived" in BucketReducer.finish(), summed over the generator's and the
+            # discriminator's exchange, max over ranks (DESIGN section 6 predicts 0.09-0.18 ms at 8 GPUs; the generator's part sits on the side stream
+            # beside the discriminator step, so this is an upper bound of what the exchange adds to the step)
+            "exposed_allreduce_ms": exposed_ms, "allreduce_backend": (dist.get_backend() if world > 1 else None),
             "final_losses": {"loss_G": loss_g, "loss_D": loss_d},
         }
         if world == 1 and not args.lpips and not args.no_cpu_baseline and args.dtype == "bf16":

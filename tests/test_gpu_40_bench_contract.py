@@ -39,3 +39,30 @@ def test_bench_glo16_and_fp32_modes_run():
     assert "GLO-16" in g["config"]["workload"] and g["value"] > 0
     f = _run("--no-cpu-baseline", "--dtype", "fp32")
     assert f["dtype"] == "fp32" and f["roofline"]["peak"] == 157.3 and 0 < f["roofline"]["frac"] < 1
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (no outer launcher) must start its N ranks itself and print ONE line with n_gpus = N. Rehearsed on
+    the one card with gloo (TFC_BENCH_BACKEND=gloo: both ranks share cuda:0); on a multi-GPU node the same command runs over RCCL."""
+    env = dict(os.environ, TFC_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["allreduce_backend"] == "gloo" and d["exposed_allreduce_ms"] >= 0.0
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+def test_bench_failing_rank_gives_nonzero_exit():
+    env = dict(os.environ, TFC_BENCH_BACKEND="no-such-backend")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

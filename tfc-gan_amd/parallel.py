@@ -24,6 +24,25 @@ def rank():
     return dist.get_rank() if dist_ready() else 0
 
 
+# ---- measurement: how long a stream waits for gradient buckets (bench.py: exposed_allreduce_ms) -------------------------------------------
+_EXPOSED = {"on": False, "pairs": []}
+
+
+def exposed_wait_begin():
+    """from now on every BucketReducer.finish() brackets its waits with an event pair on the stream it runs on"""
+    _EXPOSED["on"], _EXPOSED["pairs"] = True, []
+
+
+def exposed_wait_collect():
+    """total milliseconds between the event pairs recorded since exposed_wait_begin() (synchronises); stops the recording"""
+    _EXPOSED["on"] = False
+    pairs, _EXPOSED["pairs"] = _EXPOSED["pairs"], []
+    if not pairs:
+        return 0.0
+    torch.cuda.synchronize()
+    return float(sum(a.elapsed_time(b) for a, b in pairs))
+
+
 class FlatParams:
     """Parameters of one network flattened into ONE fp32 buffer in gradient-completion order, plus a same-shaped gradient
     buffer.  `views[name]` / `grad_views[name]` are torch-layout windows into them."""
@@ -101,8 +120,16 @@ class BucketReducer:
                     s, e, _ = self.buckets[i]
                     self.works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     p.clear()
+            timed = _EXPOSED["on"] and self.flat.grad.is_cuda
+            if timed:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
             for w in self.works:
                 w.wait()
+            if timed:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                _EXPOSED["pairs"].append((ev0, ev1))
         self.reset()
         return 1.0 / ws
 
