@@ -182,6 +182,42 @@ def test_persistent_gather_gemm_many_tiles(op, N, H, W, Cin, Cout, cfg, force_cf
         assert (from_view(dxv) - want).abs().max().item() <= 1.5 * tol(dt, want.abs().max().item())
 
 
+@pytest.mark.parametrize("op,N,H,W,Cin,Cout,cfg", [(ops.OP_CONV, 12, 70, 70, 64, 128, 0), (ops.OP_CONVT, 6, 40, 40, 64, 64, 2), (ops.OP_CONV, 16, 50, 66, 128, 64, 1),
+                                                    (ops.OP_UPCONV, 8, 48, 40, 64, 32, 2), (ops.OP_CONV, 5, 128, 128, 128, 256, 3), (ops.OP_CONVT, 9, 16, 16, 256, 128, 3),
+                                                    (ops.OP_CONV, 11, 70, 70, 64, 128, 0)])
+def test_two_half_gather_gemm_bit_identical(op, N, H, W, Cin, Cout, cfg, force_cfg):
+    """round 3: the persistent gather GEMM runs as ONE 512-thread workgroup per CU whose two 4-wave halves share the barrier sequence, half 1 running
+    (stages + 1) / 2 barrier slots behind half 0 (igemm.hip, HALVES == 2). Same tiles, same arithmetic, same order inside a tile: outputs, InstanceNorm
+    statistics (fixed-order partials) and accumulated input gradients must be BIT-IDENTICAL to the two-independent-workgroups form, including ragged last
+    rounds (work items not a multiple of 2 x CUs: one half of some workgroups pads with dummy barriers) and a half with nothing to do."""
+    dt = DT_BF16
+    seed = 4400 + Cin + Cout
+    K = Cin * (4 if op == ops.OP_CONVT else 16)
+    x = q(rnd((N, Cin, H, W), seed), dt)
+    wshape = (Cin, Cout, 4, 4) if op == ops.OP_CONVT else (Cout, Cin, 4, 4)
+    w = rnd(wshape, seed + 1, 1.0 / np.sqrt(K)).to(DEV)
+    bias = rnd((Cout,), seed + 2, 0.5).to(DEV)
+    OH, OW = ops.OUT_HW[op](H), ops.OUT_HW[op](W)
+    go = q(rnd((N, Cout, OH, OW), seed + 3), dt)
+    base = q(rnd((N, Cin, H, W), seed + 4), dt)
+    xv, gov = to_view(x, dt), to_view(go, dt)
+    pk, pkd = ops.pack_weight(dt, op, 0, w, Cin, Cout), (ops.pack_weight(dt, op, 1, w, Cin, Cout) if op != ops.OP_UPCONV else None)
+    res = []
+    for c in (cfg, cfg | 32):
+        force_cfg(c)
+        yv = ops.new_act(N, OH, OW, Cout, dt, DEV, zero=True)
+        stats = torch.zeros((N, Cout, 2), dtype=torch.float32, device=DEV)
+        ops.conv_fwd(dt, op, xv, Cin, Cout, pk, yv, bias=bias, stats=stats, flags=ops.EP_LEAKY)
+        dxv = to_view(base, dt)
+        if pkd is not None:
+            ops.conv_dgrad(dt, op, gov, N, H, W, Cin, Cout, pkd, dxv, accumulate=True)
+        torch.cuda.synchronize()
+        res.append((yv.t.clone(), stats.clone(), dxv.t.clone()))
+    assert res[0][0].float().abs().max().item() > 0 and res[0][1].abs().max().item() > 0
+    for a, b, what in zip(res[0], res[1], ("output", "statistics", "input gradient")):
+        assert torch.equal(a, b), (what, (a.float() - b.float()).abs().max().item())
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,with_bias", [(2, 33, 18, 3, 64, False), (1, 40, 70, 6, 64, True), (6, 256, 256, 6, 64, True),
                                                        (5, 200, 256, 3, 64, False)])
 def test_first_layer_weights_stationary_kernel(N, H, W, Cin, Cout, with_bias):

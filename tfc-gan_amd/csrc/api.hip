@@ -996,8 +996,8 @@ extern "C" int tfc_adam_step(void* stream, float* p, const float* g, float* m, f
   return 0;
 }
 extern "C" int tfc_debug_set_igemm_config(int cfg) {
-  REQUIRE(cfg >= -1 && cfg <= 31, "cfg must be -1 (heuristic) or tile 0 (128x128) | 1 (128x64) | 2 (128x32) | 3 (128x128, 4 n-waves) | 15 (heuristic tile), "
-          "optionally + 16 = the one-tile-per-workgroup gather GEMM instead of the persistent one");
+  REQUIRE(cfg >= -1 && cfg <= 63, "cfg must be -1 (heuristic) or tile 0 (128x128) | 1 (128x64) | 2 (128x32) | 3 (128x128, 4 n-waves) | 15 (heuristic tile), "
+          "optionally + 16 = the one-tile-per-workgroup gather GEMM instead of the persistent one, + 32 = the persistent kernel may take its two-half form");
   g_tfc_force_cfg = cfg;
   return 0;
 }

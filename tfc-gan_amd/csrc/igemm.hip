@@ -416,14 +416,31 @@ struct Tile2 {
   const unsigned char* wbase;                                    // this tile's weight stream (phase, n-block), wave part excluded
 };
 
-template <int MT, int NT, int WM, int WN, int PAT>
-__global__ void __launch_bounds__(256, 2)
+// HALVES == 2 (round 3): ONE 512-thread workgroup per CU whose two 4-wave halves each do what a workgroup of the HALVES == 1 form does (own tiles, own LDS
+// region of half_bytes) but share the workgroup barrier, and half 1 runs `shift` barrier slots BEHIND half 0. Why: two independent workgroups on a CU
+// phase-lock -- a workgroup whose SIMD partner is in its epilogue has the matrix pipe to itself, finishes its K loop early and catches up, so both end up
+// in their K loops together (sharing the pipe) and in their MFMA-free epilogues together (pipe idle: 8.2 k MFMA cycles per wave and tile inside a 27-32 k
+// cycle tile period, SQ_VALU_MFMA_BUSY 50-60 %; a start stagger re-locks within a few tiles, measured neutral in round 2). With a common barrier
+// sequence the offset cannot drift: per tile a half executes nst + 1 barriers (one per stage, one inside the epilogue), so with half 1 shifted by
+// (nst + 1) / 2 slots one half's epilogue (accumulators -> LDS -> global: no MFMA) always lies beside the other half's K-loop stages.
+// Both halves execute the SAME total number of barriers (dummy barriers pad the shorter sequence), so every wave reaches the end.
+template <int MT, int NT, int WM, int WN, int PAT, int HALVES = 1>
+__global__ void __launch_bounds__(256 * HALVES, 2)
 tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* out,
                   const float* __restrict__ bias, float* stats, float* dbg, const float* __restrict__ oscale,
-                  int flags, int NB32, int nblkN, int buf_bytes, long long phase_wbytes, int nwork) {
+                  int flags, int NB32, int nblkN, int buf_bytes, long long phase_wbytes, int nwork, int half_bytes, int shift_opts) {
+  const int shift = shift_opts & 255;
+  const bool prio = (shift_opts >> 8) & 1;                        // (A/B knob TFC_IGEMM_PRIO) raise the wave priority inside the K loop
   static_assert(WM * WN == 4 && WM * MT == 4, "4 waves, 128-pixel tile");
   static_assert(PAT != 0, "compile-time tap patterns only");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(HALVES == 1 || HALVES == 2, "one or two 4-wave halves");
+  static_assert(HALVES == 1 || 32 * NT * WN <= 128, "the two-half form has no 256-channel tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int half = HALVES == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  unsigned char* const smem = smem_all + half * half_bytes;
+  int nbar = 0;                                                  // workgroup barriers executed so far by this wave (HALVES == 2: padded to a common total)
+#define TFC_BAR() do { __builtin_amdgcn_s_barrier(); ++nbar; } while (0)
+#define TFC_SYNC() do { __syncthreads(); ++nbar; } while (0)
   typedef bf16_t T;
   constexpr int P = TFC_LDS_P;
   constexpr int NSR = TapPat<PAT>::COLS * 2;
@@ -451,12 +468,12 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   float* out_nchw = dbg;                                         // TFC_STAMP_AT writes here in the diagnostic build
   (void)out_nchw;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, r = lane & 31;
-  const int G = gridDim.x;
+  const int G = gridDim.x * HALVES;
   TFC_STAMP_AT(0);
 #ifdef TFC_STAMP
 #define TFC_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
@@ -576,10 +593,26 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   //      kept: pulling items from per-CU-pair counters (balances the pair -- the first-dispatched workgroup of a CU wins every arbitration and
   //      finishes its equal share ~25 % earlier -- but each returning atomic sits on the in-order vmcnt queue), a half-period start stagger of the
   //      second workgroup, s_setprio schemes.
+  // HALVES == 2: worker id = 2 * r(blockIdx) + half -- the two halves of a workgroup hold neighbouring tiles (shared halo columns in one L2 / L1)
+  const int worker2 = 2 * tfc_xcd_remap(blockIdx.x, gridDim.x) + half;
   auto item = [&](int k) {
+    if constexpr (HALVES == 2) return k * G + worker2 < nwork ? k * G + worker2 : -1;
     const int cnt = (nwork - k * G) < G ? (nwork - k * G) : G;   // the last round may be partial
     return (int)blockIdx.x < cnt ? k * G + tfc_xcd_remap(blockIdx.x, cnt) : -1;
   };
+  int nbar_total = 0;
+  if constexpr (HALVES == 2) {
+    // barriers each half will execute: [shift dummies (half 1)] + 1 (prologue) + (nst + 1) per tile + 1 (last statistics flush); pad to the larger
+    const int S = nst + 1, wa = worker2 - half, wb = wa + 1;
+    const int na = wa < nwork ? (nwork - wa + G - 1) / G : 0, nb = wb < nwork ? (nwork - wb + G - 1) / G : 0;
+    const int ta = na ? 2 + na * S : 0, tb = nb ? shift + 2 + nb * S : 0;
+    nbar_total = ta > tb ? ta : tb;
+    if ((half ? nb : na) == 0) {                                  // nothing for this half (a ragged last round): keep the other half's barriers company
+      for (; nbar < nbar_total; ++nbar) __builtin_amdgcn_s_barrier();
+      return;
+    }
+    if (half) for (int i = 0; i < shift; ++i) TFC_BAR();
+  }
   int round = 0;
   int w = item(0), w_next = item(1);
   Tile2 cur, nxt;
@@ -595,7 +628,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   halo_store(smem);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  TFC_BAR();
   TFC_STAMP_AT(1);
   int sc = 0;                                                    // running stage counter: halo buffer parity across tiles
 
@@ -629,6 +662,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
         for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
 
     TFC_NOW(tk0);
+    if (prio) asm volatile("s_setprio 2");                        // K loop: this wave's MFMAs go ahead of the partner wave's epilogue VALU / LDS work
     for (int st = 0; st < nst; ++st) {
       const bool last = (st + 1) == nst;
       const bool more = !last || has_next;
@@ -766,13 +800,14 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
         if (more) halo_store(smem + ((sc + 1) & 1) * bstride);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      TFC_BAR();
 #ifdef TFC_STAMP
       TFC_NOW(ts1); acc_sync += ts1 - ts0;
 #endif
       ++sc;
     }
 
+    if (prio) asm volatile("s_setprio 0");
     if (flags & TFC_EP_STATS) stat_flush();
     // ---- epilogue: accumulators (channel rows x pixel lanes) -> 16-byte units -> staged tile in LDS ----
     TFC_STAMP_AT(2);
@@ -825,7 +860,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(br[i][nt]));
     }
-    __syncthreads();
+    TFC_SYNC();
     if (ps == 0) {
       TFC_STAMP_AT(4);
 #ifdef TFC_STAMP
@@ -886,7 +921,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
         stat_lim = 2 * (d.Nout - cur.nb_blk * BN);                // floats of this n-block that exist
       }
     }
-    if (IL) __syncthreads();                                      // the staged tile is rewritten by the next pass / by the next tile's first halo store
+    if (IL) TFC_SYNC();                                           // the staged tile is rewritten by the next pass / by the next tile's first halo store
     }
     ++tcount;
     TFC_STAMP_AT(5);
@@ -899,10 +934,10 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
     w = w_next;
     w_next = item(round + 1);
   }
-  if (flags & TFC_EP_STATS) {                                     // the last tile's sums
-    __syncthreads();
-    stat_flush();
-  }
+  if (HALVES == 2 || (flags & TFC_EP_STATS)) TFC_SYNC();          // (HALVES == 2: always, so that the barrier count does not depend on the flags)
+  if (flags & TFC_EP_STATS) stat_flush();                         // the last tile's sums
+  if constexpr (HALVES == 2)
+    for (; nbar < nbar_total; ++nbar) __builtin_amdgcn_s_barrier();
 #ifdef TFC_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TFC_STAMP_AT(6);
@@ -918,6 +953,8 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
   }
 #endif
 #undef TFC_NOW
+#undef TFC_BAR
+#undef TFC_SYNC
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2983,14 +3020,32 @@ static hipError_t launch_igemm2_pat(const TfcGather& d, const void* in, const vo
   static thread_local int occ_cache = 0, occ_lds = -1;
   if (!occ_cache || occ_lds != lds) {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_igemm2_kernel<MT, NT, WM, WN, PAT>, 256, (size_t)lds) != hipSuccess || occ < 1) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_igemm2_kernel<MT, NT, WM, WN, PAT, 1>, 256, (size_t)lds) != hipSuccess || occ < 1) occ = 2;
     occ_cache = occ > 3 ? 3 : occ;
     occ_lds = lds;
   }
   const int cap = occ_cache * tfc_num_cus();
   const long long phase_wbytes = (long long)tfc_packed_bytes(d, 2);
+  if constexpr (BN <= 128) {
+    // two-half form (see the kernel): one 512-thread workgroup per CU, halves (nst + 1) / 2 barrier slots apart. Needs two LDS regions (<= 160 KiB) and
+    // enough work for both halves of every CU. MEASURED NEUTRAL (scripts/ab_halves.py, DESIGN 3.1: conv shapes x0.98-1.02, transposed x0.87-0.93, with or
+    // without s_setprio in the K loop or a deeper weight ring), so it is OFF by default: TFC_IGEMM_HALVES=2 or test config | 32 select it
+    static const int halves_env = [] { const char* e = getenv("TFC_IGEMM_HALVES"); return e ? atoi(e) : 1; }();
+    const int nst = ((d.Cin_pad * 2) / 64) * d.nplanes;
+    const int half_bytes = (lds + 255) & ~255;
+    if (halves_env == 2 && 2 * half_bytes <= 160 * 1024 && nwork >= 2 * tfc_num_cus() && (g_tfc_force_cfg < 0 || (g_tfc_force_cfg & 32))) {   // test hook: forced tiles run the two-workgroup form unless bit 5 is set
+      static const int shift_env = [] { const char* e = getenv("TFC_IGEMM_SHIFT"); return e ? atoi(e) : -1; }();
+      static const int prio_env = [] { const char* e = getenv("TFC_IGEMM_PRIO"); return e ? atoi(e) : 0; }();
+      const int shift = (shift_env >= 0 ? shift_env : (nst + 1) / 2) | (prio_env ? 256 : 0);
+      TFC_LAUNCH((tfc_igemm2_kernel<MT, NT, WM, WN, PAT, 2>), dim3(tfc_num_cus()), dim3(512), 2 * half_bytes, st, d, (const bf16_t*)in, (const uint4*)wp,
+                 (bf16_t*)out, bias, part_ws, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork, half_bytes, shift);
+      if (flags & TFC_EP_STATS) return tfc_launch_part_reduce(part_ws, stats, d.nimg, nparts, 2 * d.Nout, st);
+      return hipGetLastError();
+    }
+  }
   TFC_LAUNCH((tfc_igemm2_kernel<MT, NT, WM, WN, PAT>), dim3(nwork < cap ? nwork : cap), dim3(256), lds, st, d, (const bf16_t*)in, (const uint4*)wp,
-             (bf16_t*)out, bias, part_ws, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork);
+             (bf16_t*)out, bias, part_ws, dbg, oscale, flags, NB32, nblkN, buf_bytes, phase_wbytes, nwork, 0,
+             [] { static const int p = [] { const char* e = getenv("TFC_IGEMM_PRIO"); return e ? atoi(e) : 0; }(); return p ? 256 : 0; }());
   if (flags & TFC_EP_STATS) return tfc_launch_part_reduce(part_ws, stats, d.nimg, nparts, 2 * d.Nout, st);
   return hipGetLastError();
 }
@@ -3012,7 +3067,7 @@ static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const voi
     // bf16, compile-time tap pattern, whole 16-byte output units, NHWC output: the persistent kernel (test hook: config | 16 = one tile per workgroup)
     const int pat = match_pattern(d, 2);
     static const bool legacy_env = [] { const char* e = getenv("TFC_LEGACY_IGEMM"); return e && atoi(e) != 0; }();   // A/B knob for profiling
-    if (pat != 0 && d.Nout % 8 == 0 && !(flags & TFC_EP_TANH_NCHW) && !(g_tfc_force_cfg >= 16) && !legacy_env)
+    if (pat != 0 && d.Nout % 8 == 0 && !(flags & TFC_EP_TANH_NCHW) && !(g_tfc_force_cfg >= 0 && (g_tfc_force_cfg & 16)) && !legacy_env)
       return launch_igemm2_cfg<MT, NT, WM, WN>(pat, d, in, wp, out, bias, stats, part_ws, out_nchw, oscale, flags, st);
   }
   switch (match_pattern(d, sizeof(T))) {
