@@ -301,6 +301,28 @@ def color_jitter_thermal(real_B, params):
 # ---------------------------------------------------------------------------------------------------------------
 # adversarial losses, optimiser, the step
 # ---------------------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------------------
+# STN21 configuration (TFC-STN/TFCGAN_STN21_Original_NewModel3_Official.py, "STN"): the pieces the script takes from kornia, restated.
+# kornia is absent from the image, so these follow kornia's published behaviour (PARITY UNPINNED); the composition around them
+# (morph_triplet, the loss functions, Net.forward, the step) is lifted from the script itself by tests/golden/make_golden.py.
+# ---------------------------------------------------------------------------------------------------------------
+def morph_gradient(x):
+    """kornia.morphology.gradient(x, kernel = 3 x 3 cross) (STN:444-449) = dilation - erosion with geodesic borders: the maximum / minimum over the
+    in-image neighbours {centre, up, down, left, right} (a neighbour outside the image never wins)."""
+    def shifts(fill):
+        pad = F.pad(x, (1, 1, 1, 1), value=fill)
+        h, w = x.shape[-2:]
+        return torch.stack((pad[..., 1:h + 1, 1:w + 1], pad[..., 0:h, 1:w + 1], pad[..., 2:h + 2, 1:w + 1], pad[..., 1:h + 1, 0:w], pad[..., 1:h + 1, 2:w + 2]))
+    return shifts(float("-inf")).max(0).values - shifts(float("inf")).min(0).values
+
+
+def morph_triplet(real_A, real_B, reg_B):
+    """STN:444-459 with criterion_morph = nn.TripletMarginLoss(margin=1.0, p=2) (STN:99): anchor = 1 - grad(reg_B), positive = 1 - grad(real_A),
+    negative = 1 - grad(real_B)"""
+    crit = nn.TripletMarginLoss(margin=1.0, p=2)
+    return crit(1.0 - morph_gradient(reg_B), 1.0 - morph_gradient(real_A), 1.0 - morph_gradient(real_B))
+
+
 def loss_gan_generator(pred_fake, real_pred, valid=0.9):
     """P16:554: BCEWithLogits(pred_fake - real_pred.detach(), 0.9)."""
     x = pred_fake - real_pred.detach()

@@ -101,5 +101,129 @@ def test_stn21_step_runs_and_trains_everything():
     assert out["fake_B"].shape == (2, 3, 256, 256) and out["warped_B"].shape == (2, 3, 256, 256)
     for k, v in probes.items():
         assert not torch.equal(before[k], v.detach()), f"{k} did not move"
-    # bicubic interpolation of values in [-1, 1] overshoots by at most the kernel's negative lobes
-    assert torch.isfinite(out["warped_B"]).all() and out["warped_B"].abs().max().item() < 1.6
+    # bicubic (A = -0.75) interpolation of values in [-1, 1]: per axis the taps sum to 1 and their negative lobes to at most 2 * 0.09375 at t = 0.5 ... the
+    # absolute tap sum is <= 1.25 per axis, so |warped| <= 1.25^2 = 1.5625 for ANY theta
+    assert torch.isfinite(out["warped_B"]).all() and out["warped_B"].abs().max().item() <= 1.5625 + 1e-5
+
+
+def _portable_stn21(dev, dtype):
+    """STN21Step with the weights of tests/golden/train_step_stn21.npz: init_weights_portable seeds 101..105 in the fixture's module order (the
+    modules' state_dict order equals the lifted classes': asserted on the localiser's 160 keys), last localiser layer scaled for a visible warp"""
+    T.set_compute_dtype(dtype)
+    st = stn21.STN21Step((3, 256, 256), lpips=None, device=dev)
+    for i, m in enumerate((st.G1, st.G2, st.D1, st.D2, st.net)):
+        O.init_weights_portable(m, seed=101 + i)                  # writes through the parameter views into the flat buffers
+    with torch.no_grad():
+        st.net.fc_loc[6].weight.mul_(4.0)
+        st.net.fc_loc[6].bias.copy_(torch.tensor([0.03, -0.02, 0.04, 0.02, -0.03, -0.05], device=dev))
+    st._bump()
+    st.G1.eval(); st.G2.eval(); st.net.eval(); st.D1.train(); st.D2.train()
+    return st
+
+
+def test_stn21_step_vs_reference_golden(golden):
+    """one STN21 step against the step composed from the reference's OWN definitions (tests/golden/make_golden.py section xiii lifts
+    Net / LocalizerVIT, both generators and discriminators, morph_triplet, global_pixel_loss, global_gen_loss, global_disc_loss from STN:150-505 and
+    composes them as STN:609-672; morph.gradient and K.VisionTransformer are stand-ins, LPIPS is off on both sides): the seven losses, the warped and
+    generated images, gradients of both generators and of the localiser's MLP, and the Adam deltas -- fp32 parity mode, N = 1."""
+    g = golden("train_step_stn21")
+    try:
+        st = _portable_stn21(DEV, torch.float32)
+        assert [k for k, _ in st.net.state_dict().items()] == [str(k) for k in g["net_keys"]]
+        before = {"G2.final.2.weight": st.G2.final[2].weight.detach().clone(), "net.fc6": st.net.fc_loc[6].weight.detach().clone(),
+                  "D1.head": st.D1.model[13].weight.detach().clone()}
+        A, B = O.synthetic_pairs(1, seed=105)
+        out = st.step(A.to(DEV), B.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        T.set_compute_dtype(torch.bfloat16)
+    for k in ("loss_G", "loss_GAN", "recon_loss", "morph_loss", "loss_D", "loss_D1", "loss_D2"):
+        w = float(g[k])
+        assert abs(float(out[k]) - w) <= 3e-4 * max(1.0, abs(w)), (k, float(out[k]), w)
+    for k, got in (("warped_sub", out["warped_B"]), ("fake_A2_sub", out["fake_A2"]), ("fake_B_sub", out["fake_B"])):
+        err = (got.cpu()[:, :, ::8, ::8] - torch.from_numpy(g[k])).abs().max().item()
+        assert err <= 2e-3, (k, err)
+
+    def rel(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm()).item()
+    gv = st.gflat.grad_views
+    checks = [("g_G1_down1", gv["G1.down1.model.0.weight"]), ("g_G2_down1", gv["G2.down1.model.0.weight"]), ("g_G2_up3", gv["G2.up3.model.0.weight"][::16, ::16]),
+              ("g_fc6", gv["net.fc_loc.6.weight"]), ("g_fc6_bias", gv["net.fc_loc.6.bias"]), ("g_fc0", gv["net.fc_loc.0.weight"][::64, ::256]),
+              ("g_D1_head", st.dflat.grad_views["D1.model.13.weight"]), ("g_D2_b0", st.dflat.grad_views["D2.model.0.bias"])]
+    for k, got in checks:
+        r = rel(got.cpu(), torch.from_numpy(g[k]))
+        print(f"  {k:12s} rel-L2 {r:.3e}")
+        assert r <= 2e-2, (k, r)                                  # fp32 gradients of an N = 1 step: activation knife-edge flips (the PATCH-16 fp32 bar)
+    for k, now, want in (("d_G2_final", st.G2.final[2].weight, "G2.final.2.weight"), ("d_fc6", st.net.fc_loc[6].weight, "net.fc6"),
+                         ("d_D1_head", st.D1.model[13].weight, "D1.head")):
+        delta = (now.detach() - before[want]).cpu()
+        # the first Adam step moves every weight by ~lr * sign(g): only entries whose gradient is at round-off level may differ
+        frac = ((delta - torch.from_numpy(g[k])).abs() > 2e-5).float().mean().item()
+        assert frac <= 2e-2, (k, frac)
+
+
+def test_stn21_batch32_bf16_properties():
+    """configuration C5 at its batch (TFC-STN/0302_STN21_Devcom_NewModel.sh:3: 32) in the benchmarked arithmetic, with the LPIPS term: losses finite and in
+    range, every network moves, the step is repeatable run to run (no order-dependent sums on its gradient path)"""
+    def run():
+        torch.manual_seed(7)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            crit = T.LPIPS().to(DEV)
+        st = stn21.STN21Step((3, 256, 256), lpips=crit, device=DEV, seed=3)
+        A, B = T.synthetic_pairs(32, seed=21)
+        out = st.step(A.to(DEV), B.to(DEV))
+        torch.cuda.synchronize()
+        return st, out
+    T.set_compute_dtype(torch.bfloat16)
+    st, out = run()
+    for k in ("loss_G", "loss_GAN", "recon_loss", "perc_loss", "morph_loss", "loss_D"):
+        assert torch.isfinite(out[k]).all(), k
+    assert 0.5 < out["loss_GAN"].item() < 4.0 and 0.1 < out["loss_D"].item() < 1.0 and 0.0 < out["recon_loss"].item() < 2.0
+    assert out["morph_loss"].item() > 0 and out["perc_loss"].item() > 0
+    assert out["warped_B"].abs().max().item() <= 1.5625 + 1e-5 and out["fake_B"].abs().max().item() <= 1.0
+    gg, dg = st.gflat.grad.clone(), st.dflat.grad.clone()
+    assert torch.isfinite(gg).all() and torch.isfinite(dg).all()
+    for k in ("net.fc_loc.6.weight", "net.localization.vit.0.patch.weight", "G2.down1.model.0.weight", "G1.up3.model.0.weight"):
+        assert st.gflat.grad_views[k].abs().sum().item() > 0, k
+    st2, _ = run()
+    # the custom kernels are order-independent; the localiser's library GEMMs / softmax are the only foreign code on the path
+    r = ((st2.gflat.grad.double() - gg.double()).norm() / gg.double().norm()).item()
+    assert r <= 1e-6, r
+    assert torch.equal(st2.dflat.grad, dg)
+
+
+
+def test_stn21_two_ranks_match_one_rank(tmp_path):
+    """configuration C5 is an 8-GPU configuration (BASELINE.json configs[4]): STN21Step shards the batch over one process per GPU with the same flat
+    buffers + bucketed all-reduce as the PATCH-16 engine. Two ranks (sharing the one card, gloo), each stepping one image of a global batch of 2, must
+    end where one rank stepping both images ends: every loss of the step is a batch mean, so the rank-averaged gradient is the global-batch gradient up
+    to fp32 summation order (reference semantics: nn.DataParallel gathers the batch, STN:536-540)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "stn21_ddp_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    subprocess.run([sys.executable, worker, one], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), worker, two], check=True, env=env, timeout=600)
+    a, b = torch.load(one, weights_only=True), torch.load(two, weights_only=True)
+    assert torch.allclose(a["losses"], b["losses"], rtol=2e-5, atol=1e-6), (a["losses"], b["losses"])
+    for k in ("gg", "dg"):
+        rel = ((a[k] - b[k]).norm() / a[k].norm()).item()
+        # unlike PATCH-16 (test_gpu_20_ddp.py: <= 1e-5) the per-image work is NOT bit-identical here: the localiser runs library GEMMs whose
+        # algorithm depends on the batch size (2 images vs 1), theta moves by ~1e-7, and in fp32 mode a handful of ReLU / LeakyReLU decisions of
+        # near-zero pre-activations behind the warp flip (1.1e-3 observed; the same knife edge as the fp32 golden tests, bar 1e-2)
+        assert rel <= 5e-3, (k, rel)
+    for k in ("g", "d"):
+        frac = ((a[k] - b[k]).abs() > 2e-5).float().mean().item()
+        assert frac <= 2e-2, (k, frac)
