@@ -164,6 +164,8 @@ size_t tfc_fft_spectrum_ws_bytes(int S, int nwin);
 /* evaluation metric of TFC-GAN-FFT/Devcom_MagMSE.py:91-118 (mse_spec): per window MSE(log|fft2(a)|, log|fft2(b)|) over the FULL S x S
  * spectrum, computed from the half spectra amp_a / amp_b [nwin][S][S/2+1] of tfc_fft_spectrum; out[nwin] */
 int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out);
+/* the companion metric of TFC-GAN-FFT/eval/Eurecom/Eurecom_MagOther.py:90-118 (other_spec): mean_absolute_error of the same two log-magnitude spectra */
+int tfc_logmag_mae(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out);
 /* temperature head, P16:255-268 (vectorize_temps) over TFC-GAN-FFT/datasets_temp.py:14-35 (TempVector_PyTorch): the red channel of
  * ToPILImage(img[n]) = (uint8) trunc(x*255) (wraps mod 256) looked up in lut256 (float32(np.linspace(24,38,256)), device).
  * img: fp32 NCHW, channel 0 is read ([n*batch_stride + y*row_stride + x]); out: [N][H][W] fp32 temperatures in Celsius. */

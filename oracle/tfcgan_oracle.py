@@ -251,6 +251,13 @@ def mse_spec(real_gray, fake_gray):
     return float(np.mean((mag(real_gray) - mag(fake_gray)) ** 2))
 
 
+def other_spec(real_gray, fake_gray):
+    """TFC-GAN-FFT/eval/Eurecom/Eurecom_MagOther.py:90-118: sklearn mean_absolute_error of the same two log-magnitude spectra (uniform average over the
+    columns of equal length = the mean absolute difference)."""
+    mag = lambda im: np.log(np.abs(np.fft.fftshift(np.fft.fft2(np.asarray(im, dtype=np.float32)))))  # noqa: E731
+    return float(np.mean(np.abs(mag(real_gray) - mag(fake_gray))))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # temperature head (forward-only; P16:255-268, :587-595 over datasets_temp.py:14-35)
 # ---------------------------------------------------------------------------------------------------------------

@@ -417,6 +417,8 @@ def test_sample_spectra_and_mse_spec_vs_reference_goldens(golden):
     other = np.clip(base.astype(np.int32) + rng.integers(-40, 41, size=base.shape), 1, 255).astype(np.uint8)
     got = T.mse_spec(base, other).cpu().numpy()
     np.testing.assert_allclose(got, gm["values"], rtol=2e-3)
+    got_mae = T.other_spec(base, other).cpu().numpy()              # eval/Eurecom/Eurecom_MagOther.py:90-118, lifted the same way
+    np.testing.assert_allclose(got_mae, gm["mae_values"], rtol=2e-3)
 
 
 def _nchw(v):
@@ -569,6 +571,100 @@ def test_bf16_layers_teacher_forced_vs_storage_oracle():
     check("final wgrad", grads["final.2.weight"].cpu(), gw, BWD, 1)
     check("final bias grad", grads["final.2.bias"].cpu(), gb, BWD, 1)
     check("final dgrad", _nchw(dbg["g_u5"]), O._bf(gx), 1e-2, 1)
+    print("worst forward", worst[0], "worst backward", worst[1])
+
+
+def test_bf16_discriminator_layers_teacher_forced_vs_storage_oracle():
+    """the discriminator (P16:182-211) is 4 of the 5 network forwards of a step and runs bf16-only kernels the generator never touches:
+    the TFC_EP_LEAKY epilogue with 1/sigma and bias, the 6 -> 64 first-layer kernel (tfc_conv_c8_kernel), the pure-blur pooling, the wave-per-pixel head
+    (tfc_head_fwd_kernel), the rows-packed image gradient (tfc_dgrad_rows4_kernel), the per-image bias-gradient sums, the spectral-norm backward, and --
+    in the discriminator step, where nothing needs the image gradient -- the fused first-block backward (tfc_wgrad_c8_fused_kernel). Every one of the 4
+    spectrally normalised blocks and the head is fed to the oracle's bf16-storage model of that block with the ENGINE's stored input, the engine's
+    (u, v) snapshot and the engine's incoming gradient: forward <= 5e-4, backward <= 5e-3 rel-L2, the stored conv-output gradients element by element."""
+    T.set_compute_dtype(torch.bfloat16)
+    torch.set_num_threads(16)
+    Dc = O.init_weights_portable(O.Discriminator1((3, 256, 256)), seed=62).train()
+    A, B = O.synthetic_pairs(1, seed=63)
+    fake = torch.tanh(B * 0.7 + 0.3 * A)                              # a "generated" image: the argument whose gradient the generator step needs
+    names = T.nets.d_param_names()
+    sd = Dc.state_dict()
+    params = {k: sd[k].clone().to(DEV) for k in names}
+    bufs = {k: sd[k].clone().to(DEV) for k in sd if k.endswith("._u") or k.endswith("._v")}
+    rb, rw, rg = O._RoundBoth.apply, O._RoundFwd.apply, O._RoundBwd.apply
+    FWD, BWD = 5e-4, 5e-3
+    rng = np.random.default_rng(9)
+    g_log = torch.from_numpy(rng.standard_normal((1, 16, 16)).astype(np.float32)) * 1e-2
+
+    def run(debug, need_input_grad):
+        core = T.nets.DiscriminatorCore(T.ops.DT_BF16)
+        core.set_params({k: v.clone() for k, v in params.items()}, {k: v.clone() for k, v in bufs.items()})
+        if debug:
+            core.debug = {}
+        logits, ctx = core.forward(fake.to(DEV), A.to(DEV), power_iter=True, save=True)
+        gl = T.ops.new_act(1, 16, 16, 8, T.ops.DT_BF16, DEV, zero=True)
+        gl.t[..., 0] = g_log.to(DEV).to(torch.bfloat16)
+        grads = {k: torch.full_like(v, 7.0) for k, v in params.items()}          # overwritten, not accumulated
+        gimg = core.backward(ctx, gl, grads, need_input_grad=need_input_grad)
+        torch.cuda.synchronize()
+        return core, logits, ctx, grads, gimg
+
+    core, logits, ctx, grads, gimg = run(True, True)
+    dbg = core.debug
+    worst = [0.0, 0.0]
+
+    def check(tag, got, want, tol, slot):
+        r = _rel(got, want)
+        worst[slot] = max(worst[slot], r)
+        print(f"  {tag:40s} rel-L2 {r:.3e}")
+        assert r <= tol, (tag, r)
+
+    glb = g_log.to(torch.bfloat16).float().reshape(1, 1, 16, 16)
+    convs = [m for m in Dc.model if isinstance(m, torch.nn.Conv2d) and hasattr(m, "parametrizations")]
+    want_first = {}
+    for bi, (i, cin, cout) in enumerate(T.nets.D_BLOCKS):
+        m = convs[bi]
+        W = m.parametrizations.weight.original.detach().clone().requires_grad_(True)
+        b = m.bias.detach().clone().requires_grad_(True)
+        u, v, sig2 = (t.float().cpu() for t in ctx.sn[bi])
+        x = _nchw(ctx.ins[bi])[:, :cin].clone().requires_grad_(True)
+        sigma = torch.dot(u, W.flatten(1) @ v)                        # the engine's (u, v): sigma as torch's parametrization evaluates it (u, v constants)
+        assert abs(sigma.item() - sig2[0].item()) <= 2e-6 * abs(sigma.item()), (sigma.item(), sig2[0].item())
+        z = rg(F.conv2d(x, rw(W), padding=1) / sigma + b.view(1, -1, 1, 1))
+        h = rw(F.leaky_relu(z, 0.2))
+        raw_e = _nchw(ctx.raw[bi])
+        check(f"block{bi} SN-conv+bias+leaky fwd", raw_e, h.detach(), FWD, 0)
+        ht = h + (raw_e - h).detach()                                 # teacher forcing: continue from the ENGINE's stored activation
+        y = rb(O._blur(ht, 2))
+        y_e = _nchw(ctx.ins[bi + 1]) if bi < 3 else _nchw(ctx.p4)
+        check(f"block{bi} blur-pool fwd", y_e, y.detach(), FWD, 0)
+        g_out = _nchw(dbg[f"b{bi}.g_out"])
+        gW, gb, gx, gz = torch.autograd.grad(y, [W, b, x, z], g_out)
+        d = (_nchw(dbg[f"b{bi}.d_raw"]).double() - O._bf(gz).double()).abs()
+        n_big = int((d > 0.02 * gz.double().abs().clamp_min(1e-3 * gz.abs().max().item())).sum())
+        print(f"  block{bi} d_raw: {int((d > 0).sum())} of {d.numel()} elements differ, {n_big} by more than 2 %")
+        assert n_big == 0, (bi, n_big)
+        check(f"block{bi} wgrad (+ spectral-norm bwd)", grads[f"model.{i}.parametrizations.weight.original"].cpu(), gW, BWD, 1)
+        check(f"block{bi} bias grad", grads[f"model.{i}.bias"].cpu(), gb, BWD, 1)
+        if bi > 0:
+            check(f"block{bi} dgrad", _nchw(dbg[f"b{bi - 1}.g_out"]), O._bf(gx), BWD, 1)
+        else:
+            check("block0 image gradient (rows-packed kernel)", gimg.cpu(), gx[:, :3], BWD, 1)
+            want_first = {"w": gW, "b": gb}
+    head = Dc.model[-1]
+    Wh = head.weight.detach().clone().requires_grad_(True)
+    xh = _nchw(ctx.p4).clone().requires_grad_(True)
+    lg = rb(F.conv2d(F.pad(xh, (1, 0, 1, 0)), Wh, padding=1))
+    check("head fwd", logits.t[..., 0].float().cpu().reshape(1, 1, 16, 16), lg.detach(), FWD, 0)
+    gWh, gxh = torch.autograd.grad(lg, [Wh, xh], glb)
+    check("head wgrad", grads["model.13.weight"].cpu(), gWh, BWD, 1)
+    check("head dgrad", _nchw(dbg["b3.g_out"]), O._bf(gxh), BWD, 1)
+    # the discriminator step's form: no image gradient -> block 0 runs the FUSED first-block backward (transposed blur + LeakyReLU' + weight / bias gradient)
+    _, _, _, grads2, none = run(False, False)
+    assert none is None
+    check("block0 wgrad, fused first-block backward", grads2["model.0.parametrizations.weight.original"].cpu(), want_first["w"], BWD, 1)
+    check("block0 bias grad, fused first-block backward", grads2["model.0.bias"].cpu(), want_first["b"], BWD, 1)
+    for k in grads:                                                    # and the two forms agree with each other to round-off
+        assert _rel(grads2[k].cpu(), grads[k].cpu()) <= 2e-5, k
     print("worst forward", worst[0], "worst backward", worst[1])
 
 

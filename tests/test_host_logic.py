@@ -28,6 +28,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.tfc_abi_version() == 2
 
 
+def test_build_refuses_spilling_hand_scheduled_kernels():
+    """the asm-volatile loads of the gather GEMM / weight-gradient K loops rely on hipcc never spilling between a load and its hand-counted
+    wait; build() parses the compiler's resource remarks and fails on scratch or VGPR spills of those kernels (and only of those)."""
+    rem = ("a.hip:1:1: remark: Function Name: _Z17tfc_igemm2_kernelILi2ELi2ELi2ELi2ELi1ELi1EEv [-Rpass-analysis=kernel-resource-usage]\n"
+           "a.hip:1:1: remark:     VGPRs: 195 [-Rpass-analysis=kernel-resource-usage]\n"
+           "a.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+           "a.hip:1:1: remark:     SGPRs Spill: 27 [-Rpass-analysis=kernel-resource-usage]\n"
+           "a.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+           "a.hip:9:1: remark: Function Name: _Z15tfc_adam_kernelPf [-Rpass-analysis=kernel-resource-usage]\n"
+           "a.hip:9:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert _lib.check_no_spills(rem) == []                          # SGPR spills go to VGPRs (no memory); other kernels are not guarded
+    bad = rem.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 16").replace("VGPRs Spill: 0", "VGPRs Spill: 3")
+    got = _lib.check_no_spills(bad)
+    assert len(got) == 2 and all("tfc_igemm2_kernel" in g for g in got), got
+
+
 def test_errors_are_loud():
     lib = _lib.load()
     rc = lib.tfc_conv_fwd(None, 7, 0, None, 0, 1, 8, 8, 8, 8, None, None, 0, None, None, None, None, 0, None)

@@ -203,3 +203,5 @@ def test_mse_spec_matches_lifted_reference(golden):
     other = np.clip(base.astype(np.int32) + rng.integers(-40, 41, size=base.shape), 1, 255).astype(np.uint8)
     got = [O.mse_spec(base[i], other[i]) for i in range(3)]
     np.testing.assert_allclose(got, g["values"], rtol=1e-5)
+    got_mae = [O.other_spec(base[i], other[i]) for i in range(3)]          # eval/Eurecom/Eurecom_MagOther.py:90-118 (other_spec)
+    np.testing.assert_allclose(got_mae, g["mae_values"], rtol=1e-5)

@@ -18,12 +18,12 @@ from .stn import Warp, affine_warp, morph_gradient, morph_triplet, triplet_margi
 from .synthetic import synthetic_pairs, synthetic_temperatures  # noqa: F401
 from .inference import global_grid, load_clean_state, save_checkpoint, stitch_16_patches  # noqa: F401
 from .losses import (ContrastiveLoss, FFT_Components, calculate_ffts, color_jitter_params, color_jitter_thermal,  # noqa: F401
-                     fft_components, global_fft_loss, make_16_patches, mse_spec, patch_fft_loss, patch_first_flat_index,
+                     fft_components, global_fft_loss, make_16_patches, mse_spec, other_spec, patch_fft_loss, patch_first_flat_index,
                      patch_triplet_loss, sample_spectra, temperature_triplet_loss, vectorize_temps)
 from .models import (BlurPool, Discriminator, Discriminator1, GeneratorUNet, UNetDown, UNetUp, get_compute_dtype,  # noqa: F401
                      set_compute_dtype, weights_init_normal)
 
 __all__ = ["UNetDown", "UNetUp", "GeneratorUNet", "Discriminator1", "Discriminator", "BlurPool", "weights_init_normal",
            "make_16_patches", "ContrastiveLoss", "patch_triplet_loss", "FFT_Components", "fft_components", "calculate_ffts",
-           "patch_fft_loss", "global_fft_loss", "mse_spec", "sample_spectra", "vectorize_temps", "temperature_triplet_loss", "color_jitter_thermal",
+           "patch_fft_loss", "global_fft_loss", "mse_spec", "other_spec", "sample_spectra", "vectorize_temps", "temperature_triplet_loss", "color_jitter_thermal",
            "color_jitter_params", "synthetic_pairs", "synthetic_temperatures", "load_clean_state", "save_checkpoint", "stitch_16_patches", "global_grid", "TrainStep", "STN21Step", "LPIPS", "ImageDataset", "TestImageDataset", "DeviceLoader", "pair_resize_normalize", "Warp", "affine_warp", "morph_gradient", "morph_triplet", "triplet_margin_rows", "set_compute_dtype", "get_compute_dtype", "build", "TfcError"]

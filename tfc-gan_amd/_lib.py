@@ -39,13 +39,40 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage",
            "-Wl,-rpath,/opt/rocm/lib", "-o", SO_PATH + ".tmp"] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(l for l in res.stderr.splitlines() if "remark:" not in l)[-8000:])
+    bad = check_no_spills(res.stderr)
+    if bad:
+        raise RuntimeError("hand-scheduled kernels must not spill (their asm loads carry hand-counted waits the compiler cannot see): " + "; ".join(bad))
     os.replace(SO_PATH + ".tmp", SO_PATH)
     return SO_PATH
+
+
+# The K loops of tfc_igemm2_kernel and the weight-gradient kernels issue global_load / ds_read through asm volatile with hand-counted s_waitcnt: correct only
+# while hipcc keeps their destination registers in place (no scratch, no VGPR spill) between the load and the wait. The compiler's resource remarks
+# (-Rpass-analysis=kernel-resource-usage) are checked at every build, so a toolchain or flag change that makes one of them spill fails loudly here
+# instead of silently producing wrong convolutions.
+GUARDED_KERNELS = ("tfc_igemm2_kernel", "tfc_wgrad")
+
+
+def check_no_spills(remarks):
+    """remarks: hipcc stderr with kernel-resource-usage remarks. Returns a list of complaints about guarded kernels (empty = fine)."""
+    bad, name = [], None
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[")[0].strip()
+        elif name and any(g in name for g in GUARDED_KERNELS):
+            for key in ("ScratchSize [bytes/lane]:", "VGPRs Spill:"):
+                if key in line:
+                    val = int(line.split(key)[1].split("[")[0].strip())
+                    if val != 0:
+                        bad.append(f"{name[:80]}: {key} {val}")
+    return bad
 
 
 _c = ctypes
@@ -88,6 +115,7 @@ PROTOTYPES = {
     "tfc_fft_spectrum": (_i, [_vp, _vp, _ll, _ll, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "tfc_fft_spectrum_ws_bytes": (_sz, [_i, _i]),
     "tfc_logmag_mse": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "tfc_logmag_mae": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tfc_vectorize_temps": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _vp, _vp]),
     "tfc_row_triplet": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
     "tfc_l1_sum": (_i, [_vp, _vp, _vp, _ll, _f, _vp, _i]),

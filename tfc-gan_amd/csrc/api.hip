@@ -62,7 +62,7 @@ hipError_t tfc_launch_spectrum(const float* img, long long bs, long long cs, int
 size_t tfc_fft_ws_bytes(int S, int nwin);
 hipError_t tfc_launch_l1_sum(const float* a, const float* b, long long n, float scale, float* out, hipStream_t st);
 hipError_t tfc_launch_probe(float* out, hipStream_t st);
-hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin, float* out, hipStream_t st);
+hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin, float* out, int absolute, hipStream_t st);
 hipError_t tfc_launch_vectorize_temps(const float* x, long long bs, int rs, int N, int H, int W, const float* lut, float* out, hipStream_t st);
 hipError_t tfc_launch_row_triplet(const float* a, const float* p, const float* ng, long long rows, int W, float margin, float eps,
                                   float* loss, hipStream_t st);
@@ -777,7 +777,12 @@ extern "C" int tfc_fft_spectrum(void* stream, const float* img, long long batch_
 }
 extern "C" int tfc_logmag_mse(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out) {
   REQUIRE(amp_a && amp_b && out && (S == 64 || S == 256) && nwin > 0, "bad args");
-  CHECK_HIP(tfc_launch_logmag_mse(amp_a, amp_b, S, nwin, out, (hipStream_t)stream), "tfc_logmag_mse");
+  CHECK_HIP(tfc_launch_logmag_mse(amp_a, amp_b, S, nwin, out, 0, (hipStream_t)stream), "tfc_logmag_mse");
+  return 0;
+}
+extern "C" int tfc_logmag_mae(void* stream, const float* amp_a, const float* amp_b, int S, int nwin, float* out) {
+  REQUIRE(amp_a && amp_b && out && (S == 64 || S == 256) && nwin > 0, "bad args");
+  CHECK_HIP(tfc_launch_logmag_mse(amp_a, amp_b, S, nwin, out, 1, (hipStream_t)stream), "tfc_logmag_mae");
   return 0;
 }
 extern "C" int tfc_vectorize_temps(void* stream, const float* img, long long batch_stride, int row_stride, int N, int H, int W,

@@ -102,8 +102,11 @@ __device__ __forceinline__ int tfc_xcd_remap(int bid, int nblocks) {
 
 // Scalar reduction across workgroups without fp32 atomic round-off: every workgroup adds its partial as a DOUBLE atomic
 // (memory-side, device scope) and takes an arrival ticket; the last arriver reads the total, adds it to out[0] and re-arms
-// the slot.  One thread per workgroup calls this.  Slots are per-kernel __device__ globals: launches of the SAME kernel on
-// the same device must be stream-ordered (they are: one stream per engine).
+// the slot.  One thread per workgroup calls this.  Used for LOGGED LOSS SCALARS only (triplet, L1 / FFT, BCE, row triplet): nothing a gradient is
+// computed from goes through it (those sums use fixed-order partials, tfc_part_reduce_kernel).  Slots are per-kernel __device__ globals: two launches
+// of the SAME kernel must not overlap in time.  The engine runs two streams (nets.py), so the invariant is by kernel: BCE runs on the caller's stream
+// only, the triplet / L1 / row-triplet heads on the side stream only (engine.step: pixel_losses), and a pluggable extra_loss_G -- which also runs on
+// the side stream -- must not call tfc_bce_relativistic (it would share g_bce_slot with the main stream's call).
 struct TfcRedSlot { double acc; unsigned cnt; unsigned pad; };
 // `set`: the last arriver STORES the total (out[0] = total) instead of adding it, so the caller needs no memset launch in front of the kernel
 __device__ __forceinline__ void tfc_block_commit(TfcRedSlot* slot, double partial, float* out, bool set = false) {

@@ -160,27 +160,27 @@ tfc_l1_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, long
 // Full-spectrum log-magnitude MSE of the evaluation scripts (Devcom_MagMSE.py:91-118: mean_squared_error(log|fftshift(fft2(a))|,
 // log|fftshift(fft2(b))|)) from the HALF spectra amp_a / amp_b [W][S][S/2+1]: |F[ky][kx]| = |F[-ky][-kx]| for real input, so the columns
 // 1..S/2-1 count twice and columns 0 and S/2 once. out[w] += sum / S^2. One workgroup per (window, row block).
+template <bool ABS>
 __global__ void __launch_bounds__(256)
-tfc_logmag_mse_kernel(const float* __restrict__ a, const float* __restrict__ b, int S, float* out) {
+tfc_logmag_err_kernel(const float* __restrict__ a, const float* __restrict__ b, int S, float* out) {
   __shared__ float red[4];
   const int NB = S / 2 + 1;
-  const int w = blockIdx.x;
+  const int w = blockIdx.x;                                       // one workgroup per window, fixed summation order: no atomics, no memset
   const size_t base = (size_t)w * S * NB;
   float acc = 0.f;
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < S * NB; i += gridDim.y * 256) {
+  for (int i = threadIdx.x; i < S * NB; i += 256) {
     const int kx = i % NB;
     const float d = logf(a[base + i]) - logf(b[base + i]);
-    acc += ((kx == 0 || kx == S / 2) ? 1.f : 2.f) * d * d;
+    acc += ((kx == 0 || kx == S / 2) ? 1.f : 2.f) * (ABS ? fabsf(d) : d * d);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&out[w], (red[0] + red[1] + red[2] + red[3]) / ((float)S * (float)S));
+  if (threadIdx.x == 0) out[w] = (((red[0] + red[1]) + red[2]) + red[3]) / ((float)S * (float)S);
 }
-hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin, float* out, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * nwin, st);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tfc_logmag_mse_kernel, dim3(nwin, 8), dim3(256), 0, st, a, b, S, out);
+hipError_t tfc_launch_logmag_mse(const float* a, const float* b, int S, int nwin, float* out, int absolute, hipStream_t st) {
+  if (absolute) hipLaunchKernelGGL(tfc_logmag_err_kernel<true>, dim3(nwin), dim3(256), 0, st, a, b, S, out);
+  else hipLaunchKernelGGL(tfc_logmag_err_kernel<false>, dim3(nwin), dim3(256), 0, st, a, b, S, out);
   return hipGetLastError();
 }
 

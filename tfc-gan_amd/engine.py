@@ -78,7 +78,9 @@ class TrainStep:
 
     def step(self, real_A, real_B, neg_idx=None, extra_loss_G=None, T_B=None, B_tf=None):
         """real_A, real_B: fp32 NCHW [N,3,256,256] in [-1,1] on the GPU (this rank's shard). Returns a dict of device scalars.
-        T_B [N,256,256] + B_tf [N,3,256,256] (augmented real_B) switch the gradient-free temperature term on."""
+        T_B [N,256,256] + B_tf [N,3,256,256] (augmented real_B) switch the gradient-free temperature term on.
+        extra_loss_G(fake, real_B) -> (loss, dfake) runs on the SIDE stream beside the discriminator chain (with the triplet / FFT heads): it may use any
+        kernel of the package except tfc_bce_relativistic, whose scalar-reduction slot belongs to the main stream's call (csrc/common.h: TfcRedSlot)."""
         dt = self.dt
         self.step_no += 1
         t = self.step_no

@@ -238,7 +238,13 @@ def color_jitter_thermal(real_B, params):
     return x
 
 
-def mse_spec(real_gray, fake_gray):
+def other_spec(real_gray, fake_gray):
+    """Evaluation metric of TFC-GAN-FFT/eval/Eurecom/Eurecom_MagOther.py:90-118: per image pair sklearn mean_absolute_error(log|fftshift(fft2(real))|,
+    log|fftshift(fft2(fake))|) (= the mean absolute difference over the whole spectrum). Same inputs and return convention as mse_spec."""
+    return mse_spec(real_gray, fake_gray, absolute=True)
+
+
+def mse_spec(real_gray, fake_gray, absolute=False):
     """Evaluation metric of TFC-GAN-FFT/Devcom_MagMSE.py:91-118: per image pair MSE(log|fftshift(fft2(real))|, log|fftshift(fft2(fake))|).
     real_gray / fake_gray: uint8 grayscale images [N,256,256] (tensor or array, as cv2.imread(path, 0) yields). Returns [N] fp32."""
     def prep(g):
@@ -248,4 +254,4 @@ def mse_spec(real_gray, fake_gray):
         return (t + 0.5) / 255.0                      # the spectrum kernel truncates x*255 back to the same uint8
     a, _ = ops.fft_spectrum(prep(real_gray), 256, 1, 1, shift=False)
     b, _ = ops.fft_spectrum(prep(fake_gray), 256, 1, 1, shift=False)
-    return ops.logmag_mse(a, b)
+    return ops.logmag_mse(a, b, absolute=absolute)

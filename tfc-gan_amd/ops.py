@@ -419,10 +419,12 @@ def fft_spectrum(img, S, wins_x, wins_y, shift=True, direct=False):
     return amp, pha
 
 
-def logmag_mse(amp_a, amp_b):
+def logmag_mse(amp_a, amp_b, absolute=False):
+    """per window mean squared (or absolute) difference of the log-magnitude spectra over the FULL S x S spectrum"""
     nwin, S = amp_a.shape[0], amp_a.shape[1]
     out = torch.empty(nwin, dtype=torch.float32, device=amp_a.device)
-    check(lib().tfc_logmag_mse(stream_ptr(), _p(amp_a), _p(amp_b), S, nwin, _p(out)), "tfc_logmag_mse")
+    fn = lib().tfc_logmag_mae if absolute else lib().tfc_logmag_mse
+    check(fn(stream_ptr(), _p(amp_a), _p(amp_b), S, nwin, _p(out)), "tfc_logmag_mae" if absolute else "tfc_logmag_mse")
     return out
 
 
