@@ -72,6 +72,12 @@ int tfc_conv_pack_planned(void* stream, int dt, const void* plan_dev, int njobs,
 int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout,
                  const void* packed, void* y, int y_pitch, const float* bias, float* stats, float* out_nchw, const float* oscale, int flags,
                  float* part_ws /* nullable unless TFC_EP_STATS */);
+/* ---- the FIRST convolution of either network (UNetDown(channels, 64, normalize=False) P16:140; discriminator_block(2 * channels, 64) P16:194): bf16,
+ * Cin <= 8 (x: NHWC8), Cout == 64, weights-stationary kernel. Same result as tfc_conv_fwd(TFC_OP_CONV) with flags in {TFC_EP_BIAS, TFC_EP_LEAKY}; in
+ * addition sign_mask (nullable, 8-byte aligned): uint8 [N][H-1][W-1][8], bit c of a pixel's 64-bit word = (stored y[c] > 0) -- all that the backward of
+ * the block needs of y when only its weight / bias gradient is wanted (tfc_first_block_bwd_wgrad reads 8 bytes per pixel instead of 128). */
+int tfc_conv_first_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const void* packed, void* y, int y_pitch,
+                       const float* bias, const float* oscale, int flags, uint8_t* sign_mask);
 /* ---- PatchGAN head forward, P16:201-202: ZeroPad2d((1,0,1,0)) + Conv2d(C,1,k4,p1,no bias) as a wave-per-pixel dot product
  * (w: torch-layout fp32 [1][C][4][4], y: [N][H][W][y_pitch] channel 0). Same result as tfc_conv_fwd(TFC_OP_PADCONV, Cout=1). */
 int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* w,
@@ -210,10 +216,13 @@ int tfc_row_triplet_grad(void* stream, const float* anchor, const float* positiv
  * (and bias) gradient, it is never written: = tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad(TFC_OP_CONV) in one kernel, same bits.
  * x: NHWC8 input image [N][H][W][8]; y: the stored conv output [N][H-1][W-1] (its sign is all that is read: pre- or post-activation);
  * dy_pooled: gradient of the pooled output [N][Ho][Wo], Ho = (H-2)/2+1; dw: torch-layout gradient [Cout][Cin][4][4] (=/+=);
- * bias_sums (nullable, needs part_ws): float[N][Cout] += per-image sums of the conv-output gradient; ws: tfc_conv_wgrad_ws_bytes() of scratch (zeroed once). ---- */
+ * bias_sums (nullable, needs part_ws): float[N][Cout] += per-image sums of the conv-output gradient; ws: tfc_conv_wgrad_ws_bytes() of scratch (zeroed once).
+ * sign_mask (nullable): the word tfc_conv_first_fwd left; when given, y is not read (and may be NULL). The transposed blur runs as a GEMM against the
+ * tile's tap matrix on the matrix core: d_raw may differ from the unfused chain's by 1 bf16 ulp on rare elements (different fp32 summation order). ---- */
 int tfc_first_block_bwd_supported(int dt, int Cin, int Cout);
 int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, int x_pitch, const void* y, int y_pitch, const void* dy_pooled, int dyp_pitch, int N, int H,
-                              int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums, float* part_ws);
+                              int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums, float* part_ws,
+                              const uint8_t* sign_mask);
 
 /* ---- input pipeline: ImageDataset.__getitem__, TFC-GAN-FFT/datasets_temp.py:38-123 --------------------------
  * A decoded file is one RGB uint8 image [H][W][3] with the visible image A in columns [0, xsplit) and the thermal image B in [xsplit, W),

@@ -250,11 +250,17 @@ def test_first_layer_weights_stationary_kernel(N, H, W, Cin, Cout, with_bias):
     assert (dw.cpu() - 2 * gw).abs().max().item() <= 2 * wtol
 
 
-@pytest.mark.parametrize("N,S,Cin,disc", [(2, 40, 3, False), (1, 70, 6, True), (3, 256, 6, True), (2, 256, 3, False)])
-def test_fused_first_block_backward_equals_unfused_chain(N, S, Cin, disc):
+@pytest.mark.parametrize("valu", [True, False])
+@pytest.mark.parametrize("N,S,Cin,disc", [(2, 40, 3, False), (1, 70, 6, True), (3, 256, 6, True), (2, 256, 3, False), (2, 251, 6, True), (1, 18, 3, True)])
+def test_fused_first_block_backward_equals_unfused_chain(N, S, Cin, disc, valu, monkeypatch):
     """[BlurPool]^T -> LeakyReLU' -> weight / bias gradient of the first block in one kernel (the 266 MB gradient of the conv output is never
-    written) against the chain it replaces, tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad: the same d_raw bits go into the MFMAs, only the
-    split-K summation order differs (fp32 round-off). Reflect aliases on all four borders, partial tiles, with and without accumulate."""
+    written) against the chain it replaces, tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad. Two forms: the VALU form (TFC_FIRST_BWD_VALU=1) puts the
+    same d_raw bits into the MFMAs, only the split-K summation order differs (fp32 round-off: 2e-5); the product form runs the transposed blur as
+    a GEMM against the tile's tap matrix on the matrix core (round 3) -- the <= 9 exact products per element are added in another order, so an
+    element of d_raw may round to the neighbouring bf16 (<= 1 ulp on rare elements): 2e-4 on the weight gradient. Reflect aliases on all four
+    borders, partial tiles and sizes whose last TWO tile rows are border rows (S = 251, 18), with and without accumulate."""
+    monkeypatch.setenv("TFC_FIRST_BWD_VALU", "1" if valu else "0")
+    rtol = 2e-5 if valu else 2e-4
     dt = DT_BF16
     assert ops.first_block_bwd_supported(dt, Cin, 64)
     H = S - 1
@@ -271,15 +277,35 @@ def test_fused_first_block_backward_equals_unfused_chain(N, S, Cin, disc):
     r1 = torch.zeros((N, 64), device=DEV)
     ws = ops.first_block_bwd_wgrad(dt, xv, yv, gv, Cin, 64, dw1, slope=0.2, ws=ws, bias_sums=r1 if disc else None)
     scale = dw0.abs().max().item()
-    assert (dw1 - dw0).abs().max().item() <= 2e-5 * scale + 1e-6, (dw1 - dw0).abs().max().item() / scale
+    assert (dw1 - dw0).abs().max().item() <= rtol * scale + 1e-6, (dw1 - dw0).abs().max().item() / scale
     if disc:
         assert torch.allclose(r1, r0, rtol=1e-4, atol=1e-3 * r0.abs().max().item())
     ops.first_block_bwd_wgrad(dt, xv, yv, gv, Cin, 64, dw1, slope=0.2, ws=ws, accumulate=True)
-    assert (dw1 - 2 * dw0).abs().max().item() <= 4e-5 * scale + 1e-6
+    assert (dw1 - 2 * dw0).abs().max().item() <= 2 * rtol * scale + 1e-6
     # and the generic path still finds its accumulator zeroed
     dw2 = torch.zeros_like(dw0)
     ops.conv_wgrad(dt, ops.OP_CONV, xv, d_raw, Cin, 64, dw2, ws=ws)
     assert torch.allclose(dw2, dw0, rtol=1e-5, atol=1e-6 * scale)
+    if not valu:
+        # the sign word the first convolution can leave (tfc_conv_first_fwd): same bits as (y > 0), and the backward that reads it instead of y
+        # gives the SAME weight / bias gradient bits as the one that derives the signs from y itself
+        w1 = rnd((64, Cin, 4, 4), 8, 0.2).to(DEV)
+        pk = ops.pack_weight(dt, ops.OP_CONV, 0, w1, Cin, 64)
+        y2 = ops.new_act(N, H, H, 64, dt, DEV)
+        mask = torch.zeros((N, H, H, 8), dtype=torch.uint8, device=DEV)
+        bias = rnd((64,), 9, 0.3).to(DEV)
+        ops.conv_first_fwd(dt, xv, Cin, 64, pk, y2, bias=bias, flags=ops.EP_LEAKY, sign_mask=mask)
+        y3 = ops.new_act(N, H, H, 64, dt, DEV)
+        ops.conv_fwd(dt, ops.OP_CONV, xv, Cin, 64, pk, y3, bias=bias, flags=ops.EP_LEAKY)
+        assert torch.equal(y2.t, y3.t)
+        want_bits = (y2.t.float() > 0).reshape(N, H, H, 8, 8).to(torch.int32)
+        want = (want_bits << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+        assert torch.equal(mask, want)
+        dwa, dwb = torch.zeros_like(dw0), torch.zeros_like(dw0)
+        ra, rb2 = torch.zeros((N, 64), device=DEV), torch.zeros((N, 64), device=DEV)
+        ops.first_block_bwd_wgrad(dt, xv, y2, gv, Cin, 64, dwa, slope=0.2, ws=ws, bias_sums=ra)
+        ops.first_block_bwd_wgrad(dt, xv, None, gv, Cin, 64, dwb, slope=0.2, ws=ws, bias_sums=rb2, sign_mask=mask)
+        assert torch.equal(dwa, dwb) and torch.equal(ra, rb2)
 
 
 def test_planned_pack_equals_single_pack():

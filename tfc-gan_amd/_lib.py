@@ -125,7 +125,8 @@ PROTOTYPES = {
     "tfc_morph_grad_bwd": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i]),
     "tfc_row_triplet_grad": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _f, _f, _vp, _vp]),
     "tfc_first_block_bwd_supported": (_i, [_i, _i, _i]),
-    "tfc_first_block_bwd_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
+    "tfc_first_block_bwd_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
+    "tfc_conv_first_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "tfc_resize_plan_bytes": (_sz, [_i, _i, _i]),
     "tfc_resize_plan_build": (_i, [_i, _i, _i, _vp]),
     "tfc_pair_resize_ws_bytes": (_sz, [_i, _i, _i]),

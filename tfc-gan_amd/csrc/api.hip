@@ -38,6 +38,9 @@ int tfc_nb32_padded(int nout);
 size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st);
+bool tfc_conv_c8_eligible(const TfcGather& d, int flags);
+hipError_t tfc_launch_conv_c8(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, const float* oscale, int flags,
+                              unsigned char* sign_mask, hipStream_t st);
 hipError_t tfc_launch_wgrad(int dt, const TfcGather& d, const void* dO, const void* in, float* dwacc, void* slab, int Nn_pad, int Nn_real, int Cw_real, hipStream_t st, TfcWgradFin* fin);
 hipError_t tfc_launch_dgrad_rows4(const void* dy, int dy_pitch, int N, int H, int W, const float* w, int Cin, const float* oscale, int NC, float* dx, hipStream_t st);
 hipError_t tfc_launch_upconv_head(const void* x, int x_pitch, int N, int H, int W, const float* w, const float* bias, int Cout, float* out, hipStream_t st);
@@ -414,6 +417,7 @@ extern "C" int tfc_conv_pack(void* stream, int dt, int op, int pass, const float
   return 0;
 }
 
+extern "C" int tfc_first_block_bwd_supported(int dt, int Cin, int Cout);
 static double conv_flop(int op, int N, int H, int W, int Cin, int Cout) {
   const double oh = out_hw(op, H), ow = out_hw(op, W);
   const double taps = (op == TFC_OP_CONVT) ? 4.0 : (op == TFC_OP_CONV3 ? 9.0 : 16.0);
@@ -446,6 +450,24 @@ extern "C" int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_p
     if (int e = check_desc(d, dt)) return e;
     CHECK_HIP(tfc_launch_igemm(dt, d, x, (const char*)packed + phase_packed_offset(dt, op, 0, Cin, Cout, ph), y, bias, stats, part_ws, out_nchw, oscale, flags, (hipStream_t)stream), "tfc_conv_fwd");
   }
+  return 0;
+}
+
+extern "C" int tfc_conv_first_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const void* packed, void* y,
+                                  int y_pitch, const float* bias, const float* oscale, int flags, uint8_t* sign_mask) {
+  REQUIRE(dt == TFC_DT_BF16 && tfc_first_block_bwd_supported(dt, Cin, Cout), "tfc_conv_first_fwd: bf16, Cin <= 8, Cout == 64 (use tfc_conv_fwd otherwise)");
+  if (int e = check_common(dt, TFC_OP_CONV, N, H, W, Cin, Cout)) return e;
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(packed, "packed")) return e;
+  if (int e = check_ptr16(y, "y")) return e;
+  REQUIRE(x_pitch == 8 && y_pitch >= Cout && y_pitch % 8 == 0, "pitches: x %d (must be 8), y %d", x_pitch, y_pitch);
+  REQUIRE((flags & ~(TFC_EP_BIAS | TFC_EP_LEAKY)) == 0 && (!(flags & TFC_EP_BIAS) || bias), "flags: TFC_EP_BIAS (with bias) | TFC_EP_LEAKY only");
+  REQUIRE(!sign_mask || (((uintptr_t)sign_mask) & 7) == 0, "sign_mask must be 8-byte aligned");
+  TfcGather d;
+  if (int e = build_desc(TFC_OP_CONV, 0, 0, N, H, W, Cin, Cout, x_pitch, y_pitch, &d, nullptr)) return e;
+  REQUIRE(tfc_conv_c8_eligible(d, flags), "unexpected descriptor");
+  ProfScope prof(0, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), (hipStream_t)stream, TFC_OP_CONV, 0, N, H, W, Cin, Cout);
+  CHECK_HIP(tfc_launch_conv_c8(d, x, packed, y, bias, oscale, flags, sign_mask, (hipStream_t)stream), "tfc_conv_first_fwd");
   return 0;
 }
 
@@ -602,19 +624,22 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
 
 // ---- fused first-block backward --------------------------------------------------------------------------------------------------------
 hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
-                                      void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real, hipStream_t st);
+                                      void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real,
+                                      const unsigned char* sign_mask, hipStream_t st);
+
 extern "C" int tfc_first_block_bwd_supported(int dt, int Cin, int Cout) { return dt == TFC_DT_BF16 && Cin > 0 && Cin <= 8 && Cout == 64 ? 1 : 0; }
 extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, int x_pitch, const void* y, int y_pitch, const void* dy_pooled, int dyp_pitch,
                                          int N, int H, int W, int Cin, int Cout, float slope, void* ws, float* dw, int accumulate, float* bias_sums,
-                                         float* part_ws) {
+                                         float* part_ws, const uint8_t* sign_mask) {
   REQUIRE(tfc_first_block_bwd_supported(dt, Cin, Cout), "fused first-block backward: bf16, Cin <= 8, Cout == 64 (dt=%d Cin=%d Cout=%d)", dt, Cin, Cout);
   if (int e = check_common(dt, TFC_OP_CONV, N, H, W, Cin, Cout)) return e;
-  REQUIRE(x && y && dy_pooled && ws && dw, "null argument");
+  REQUIRE(x && (y || sign_mask) && dy_pooled && ws && dw, "null argument (y may be null only when sign_mask is given)");
   REQUIRE(!bias_sums || part_ws, "bias_sums needs part_ws");
-  REQUIRE(x_pitch == 8 && y_pitch >= 64 && y_pitch % 8 == 0 && dyp_pitch >= 64 && dyp_pitch % 8 == 0, "pitches: x %d (must be 8), y %d, dy %d", x_pitch, y_pitch, dyp_pitch);
+  REQUIRE(x_pitch == 8 && (!y || (y_pitch >= 64 && y_pitch % 8 == 0)) && dyp_pitch >= 64 && dyp_pitch % 8 == 0, "pitches: x %d (must be 8), y %d, dy %d", x_pitch, y_pitch, dyp_pitch);
   REQUIRE(H >= 4 && W >= 4, "reflect padding of the blur needs a 3 x 3 activation at least");
   if (int e = check_ptr16(x, "x")) return e;
-  if (int e = check_ptr16(y, "y")) return e;
+  if (y) { if (int e = check_ptr16(y, "y")) return e; }
+  if (sign_mask) REQUIRE((((uintptr_t)sign_mask) & 7) == 0, "sign_mask must be 8-byte aligned");
   if (int e = check_ptr16(dy_pooled, "dy_pooled")) return e;
   hipStream_t st = (hipStream_t)stream;
   TfcGather d;
@@ -626,7 +651,7 @@ extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, in
     // class 3, not 1: this launch also carries the (VALU-bound) transposed blur that used to be an elementwise pass of its own -- keeping it out of
     // the weight-gradient class keeps that class comparable across rounds
     ProfScope prof(3, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), st, TFC_OP_CONV, 2, N, H, W, Cin, Cout);
-    CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, part_ws, slope, Cout, Cin, st),
+    CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, part_ws, slope, Cout, Cin, sign_mask, st),
               "tfc_first_block_bwd_wgrad");
   }
   {

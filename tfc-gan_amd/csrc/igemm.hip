@@ -967,7 +967,7 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4)
 tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* __restrict__ out,
-                   const float* __restrict__ bias, const float* __restrict__ oscale, int leaky, int NB32, int nwork) {
+                   const float* __restrict__ bias, const float* __restrict__ oscale, int leaky, int NB32, int nwork, unsigned char* __restrict__ sign_mask) {
   constexpr int P = TFC_LDS_P, PS = 16, MT = 2;
   constexpr int HB = TFC_MAX_HH * P * PS;                        // one halo buffer (4224 B)
   constexpr int ROWP = 64 * 2 + 16;                              // staged output tile: 64 channels per pixel row + pad
@@ -1056,6 +1056,16 @@ tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4
       if (a < d.GH && b < d.GW && u * 8 < d.Nout) {
         const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * ROWP + u * 16);
         store_stream16(out + ((size_t)(img * d.OH + a + d.OOY) * d.OW + b + d.OOX) * d.out_pitch + u * 8, v);
+        if (sign_mask) {
+          // one bit per stored value, (value > 0): all the first block's backward needs of this 266 MB tensor when only its weight / bias gradient is
+          // wanted (tfc_wgrad_c8_fusedm_kernel reads 8 bytes per pixel instead of 128). Byte u of pixel (a, b) = channels 8u .. 8u+7.
+          float f[8];
+          unpack16<bf16_t>(v, f);
+          unsigned bits = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bits |= (f[e] > 0.f ? 1u : 0u) << e;
+          sign_mask[((size_t)(img * d.OH + a) * d.OW + b) * 8 + u] = (unsigned char)bits;
+        }
       }
     }
     if (!has1) break;
@@ -2259,6 +2269,288 @@ tfc_wgrad_c8_fused_kernel(const TfcGather d, const bf16_t* __restrict__ yact, in
     for (int q4 = 0; q4 < 4; ++q4)
       ps[(ni * 4 + q4) * 64] = make_float4(acc[ni][4 * q4], acc[ni][4 * q4 + 1], acc[ni][4 * q4 + 2], acc[ni][4 * q4 + 3]);
 }
+// ---------------------------------------------------------------------------------------------------
+// The same fused first-block backward with the transposed blur ON THE MATRIX CORE (round 3). The kernel above spends ~1,200 VALU instructions per
+// thread and tile on the 2 x 2 (3 x 3 at the reflect borders) taps -- 5.5 k cycles per tile against 0.5 k for its 16 weight-gradient MFMAs: VALU-bound
+// at 170 us where its 366 MB of HBM traffic need ~80. The transposed blur of a tile is a LINEAR map from the 7 x 11 window of the pooled gradient
+// to the tile's 8 x 16 pixels, the same for every channel:   g[p][c] = sum_q T[p][q] * win[q][c],   T[p][q] = wrow[ty][dy] * wcol[tx][dx].
+// Its entries are products of sums of {1/8, 3/8} -- exactly representable in bf16 -- and win is bf16, so the products are exact in fp32 and only the
+// ORDER of the <= 9 additions differs from the VALU form (fp32 round-off; 1 bf16 ulp on rare elements after rounding). As a GEMM per tile:
+// 128 pixels x 80 (77 + 3 zero) window positions x 64 channels = 40 MFMAs 32x32x16 -- 10 per wave, 320 cycles. Operands: the window is staged as two
+// 32-channel planes [q][32] of 64-byte rows and fetched with the transposing LDS read the weight-gradient loop already uses (A, rows = channels);
+// T lives in LDS as Tt[pixel][q] (176-byte rows: conflict-free 16-byte reads) and is rebuilt only when the tile's border class changes (first /
+// interior / last tile rows and columns; tiles are dealt contiguously); lanes hold 16 channels of ONE pixel, so the LeakyReLU' mask comes from a
+// 64-bit sign word per pixel that the threads build from their (coalesced, natural-layout) loads of the stored activation.
+// ---------------------------------------------------------------------------------------------------
+template <bool MASK>                                              // MASK: the forward pass left sign words (8 bytes per pixel are read instead of 128)
+__global__ void __launch_bounds__(256, 2)
+tfc_wgrad_c8_fusedm_kernel(const TfcGather d, const bf16_t* __restrict__ yact, int y_pitch, const bf16_t* __restrict__ dyp, int dyp_pitch, int Ho, int Wo,
+                           const bf16_t* __restrict__ in, float4* __restrict__ slab, float* rstats, float slope, int wpi, int per,
+                           const unsigned char* __restrict__ sign_mask) {
+  constexpr int ROWB = 64;
+  constexpr int DO_BYTES = 2 * 128 * ROWB;
+  constexpr int HALO_BYTES = (TFC_MAX_HH * TFC_MAX_HW * 16 + 255) & ~255;
+  constexpr int WH = 7, WW = 11, NQ = 80;                          // pooled-gradient window: 77 pixels (+ 3 zero rows: K = 5 x 16)
+  constexpr int PLANE = NQ * ROWB, WIN_BYTES = 2 * PLANE;          // two 32-channel planes [q][32 channels]
+  constexpr int TP = 176, TT_BYTES = 128 * TP;                     // Tt[pixel][88 bf16]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[DO_BYTES + 2 * HALO_BYTES + WIN_BYTES + TT_BYTES + 128 * 8 + 24 * 16 + 4 * 64 * 4];
+  unsigned char* halo0 = smem + DO_BYTES;
+  unsigned char* winb = halo0 + 2 * HALO_BYTES;
+  unsigned char* ttb = winb + WIN_BYTES;
+  unsigned char* maskb = ttb + TT_BYTES;                           // [128 pixels][8 bytes]: bit c of pixel p = (stored activation of channel c > 0)
+  float4* wrow = reinterpret_cast<float4*>(maskb + 128 * 8);       // [8] tap weights of pooled rows o0-1, o0, o0+1
+  float4* wcol = wrow + 8;                                         // [16]
+  float* sbias = reinterpret_cast<float*>(wcol + 16);              // [4 waves][64]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TfcPlane& pd = d.plane[0];
+  const int sp = blockIdx.x;
+  const int tpi = d.tiles_y * d.tiles_x;
+  const int wimg = sp / wpi, wj = sp - wimg * wpi;
+  const int t0 = wimg * tpi + wj * per, t1 = (wj * per + per) < tpi ? (t0 + per) : (wimg + 1) * tpi;
+  f32x16_t acc[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[ni][j] = 0.f;
+  for (int i = tid; i < 2 * 3 * 4; i += 256) {                     // window rows 77..79 of both planes stay zero for the whole launch
+    const int pl = i / 12, r = i % 12;
+    *reinterpret_cast<uint4*>(winb + pl * PLANE + 77 * ROWB + r * 16) = make_uint4(0, 0, 0, 0);
+  }
+  // a workgroup's tiles are consecutive tiles of ONE image: (tile row, tile column) advance incrementally and every per-thread index that does not
+  // depend on the tile is computed once (the integer divisions of a per-tile decode were a third of the VALU work of a tile)
+  const int img = wimg;
+  int wrow_i[3], wcol_i[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const int wp = (tid + i * 256) >> 3; wrow_i[i] = wp / WW; wcol_i[i] = wp - wrow_i[i] * WW; }
+  const int hy_t = tid / pd.hw, hx_t = tid - hy_t * pd.hw;
+  // Loads run DEPTH tiles ahead of their use, in DEPTH register stages (a tile is a few microseconds of work and its loads are scattered rows of three
+  // tensors: one tile of read-ahead left every tile waiting for most of a memory round trip). With sign words a stage is 18 VGPRs: two stages; with the
+  // stored activation (64 more bytes per thread) one.
+  constexpr int DEPTH = MASK ? 2 : 1;
+  struct Stage { uint4 vy[4], vw[3], vha; uint2 vm; };
+  Stage S0, S1;
+  auto tile_load = [&](Stage& S, int a0, int b0) {
+    uint4 (&vy)[4] = S.vy; uint4 (&vw)[3] = S.vw; uint4& vha = S.vha; uint2& vm = S.vm;
+    if constexpr (MASK) {                                         // 8 bytes per pixel instead of the 128 bytes of the stored activation
+      vm = make_uint2(0, 0);
+      if (tid < 128) {
+        const int a = a0 + (tid >> 4), b = b0 + (tid & 15);
+        if (a < d.GH && b < d.GW) vm = *reinterpret_cast<const uint2*>(sign_mask + ((size_t)(img * d.OH + a) * d.OW + b) * 8);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;                           // (ni * 128 + px) * 4 + g
+        const int g = idx & 3, px = (idx >> 2) & 127, ni = idx >> 9;
+        const int a = a0 + (px >> 4), b = b0 + (px & 15);
+        vy[i] = make_uint4(0, 0, 0, 0);
+        if (a < d.GH && b < d.GW) vy[i] = load_stream16(yact + ((size_t)(img * d.OH + a) * d.OW + b) * y_pitch + ni * 32 + g * 8);
+      }
+    }
+    const int oyb = a0 / 2 - 1, oxb = b0 / 2 - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + i * 256;                             // window pixel * 8 + unit
+      const int u = idx & 7;
+      const int oy = oyb + wrow_i[i], ox = oxb + wcol_i[i];
+      vw[i] = make_uint4(0, 0, 0, 0);
+      if (wrow_i[i] < WH && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) vw[i] = *reinterpret_cast<const uint4*>(dyp + ((size_t)(img * Ho + oy) * Wo + ox) * dyp_pitch + u * 8);
+    }
+    vha = make_uint4(0, 0, 0, 0);
+    if (tid < pd.hh * pd.hw) {
+      const int hy = hy_t, hx = hx_t;
+      const int y = a0 + pd.dy0 + hy, x = b0 + pd.dx0 + hx;
+      if (y >= 0 && y < d.IH && x >= 0 && x < d.IW) vha = *reinterpret_cast<const uint4*>(in + ((size_t)(img * d.IH + y) * d.IW + x) * d.in_pitch);
+    }
+  };
+  auto taps3 = [&](int q, int L, int Lo) {                         // as in the VALU form: tap weights of pooled rows o0-1, o0, o0+1, reflect aliases merged
+    float w3[3] = {0.f, 0.f, 0.f};
+    if (q < L) {
+      const int o0 = (q + 1) >> 1;
+      for (int a = 0; a < 4; ++a) {
+        if ((a == 1 && q != 1) || (a == 2 && q != L - 2) || (a == 3 && q != L - 3)) continue;
+        const int pq = a == 0 ? q : (a == 1 ? -1 : (a == 2 ? L : L + 1));
+        for (int k = 0; k < 4; ++k) {
+          const int t = pq + 1 - k;
+          if (t < 0 || (t & 1) || (t >> 1) >= Lo) continue;
+          const int dd = (t >> 1) - o0 + 1;
+          if (dd == 0) w3[0] += fbw(k); else if (dd == 1) w3[1] += fbw(k); else if (dd == 2) w3[2] += fbw(k);
+        }
+      }
+    }
+    return make_float4(w3[0], w3[1], w3[2], 0.f);
+  };
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trA = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;
+  const int trB = (8 * hk + q) * 16 + cb16 * 32 + p * 8;
+  auto tr16 = [&](const unsigned char* p0, int rowb4) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + rowb4));
+    uint4 r;
+    r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  };
+  float bsum[2][16];                                              // bias-gradient sums of this lane's 2 x 16 channels (channel = cb*32 + (j&3) + 8(j>>2) + 4h)
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bsum[cb][j] = 0.f;
+  const int hh = lane >> 5, pl = 32 * wave + (lane & 31);          // this lane's pixel of the tile in the blur GEMM (wave = 32-pixel block = 2 tile rows)
+  int key_a = -2, key_b = -2;                                      // border class of the tile Tt was built for
+
+  int cur = 0;
+  auto body = [&](Stage& S, int a0, int b0, bool prefetch, int pa0, int pb0) {
+    uint4 (&vy)[4] = S.vy; uint4 (&vw)[3] = S.vw; uint4& vha = S.vha; uint2& vm = S.vm;
+    // A. window planes, halo, sign words of this tile -> LDS
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < WH * WW * 8) { const int u = idx & 7, wp = idx >> 3; *reinterpret_cast<uint4*>(winb + (u >> 2) * PLANE + wp * ROWB + (u & 3) * 16) = vw[i]; }
+    }
+    if (tid < TFC_MAX_HH * TFC_MAX_HW) *reinterpret_cast<uint4*>(halo0 + cur * HALO_BYTES + tid * 16) = vha;
+    // the tap tables (and the tap matrix built from them) change only with the tile's border class: interior tiles share one set
+    const int ka = (a0 == 0 || a0 + TFC_TILE_H > d.GH - 3) ? a0 : -1, kb = (b0 == 0 || b0 + TFC_TILE_W > d.GW - 3) ? b0 : -1;
+    const bool rebuild = ka != key_a || kb != key_b;
+    if (rebuild) {
+      if (tid < 8) wrow[tid] = taps3(a0 + tid, d.GH, Ho);
+      else if (tid < 24) wcol[tid - 8] = taps3(b0 + tid - 8, d.GW, Wo);
+    }
+    if constexpr (MASK) {
+      if (tid < 128) *reinterpret_cast<uint2*>(maskb + tid * 8) = vm;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        const int g = idx & 3, px = (idx >> 2) & 127, ni = idx >> 9;
+        float yv[8];
+        unpack16<bf16_t>(vy[i], yv);
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bits |= (yv[e] > 0.f ? 1u : 0u) << e;
+        maskb[px * 8 + ni * 4 + g] = (unsigned char)bits;
+      }
+    }
+    __syncthreads();
+    // B. the tap matrix of this tile's border class (rows / columns next to a reflect border or beyond the image differ from the interior ones)
+    if (rebuild) {
+      key_a = ka; key_b = kb;
+      for (int i = tid; i < TT_BYTES / 16; i += 256) *reinterpret_cast<uint4*>(ttb + i * 16) = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      if (tid < 128) {
+        const int ty = tid >> 4, tx = tid & 15;
+        const float4 wr = wrow[ty], wc = wcol[tx];
+        const float wrv[3] = {wr.x, wr.y, wr.z}, wcv[3] = {wc.x, wc.y, wc.z};
+        const int wy = ((ty + 1) >> 1) + 1, wx = ((tx + 1) >> 1) + 1;      // window position of the (oy0, ox0) tap: tile-invariant (a0, b0 are multiples of 8 / 16)
+        bf16_t* trow = reinterpret_cast<bf16_t*>(ttb + tid * TP);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float w = wrv[dy] * wcv[dx];
+            if (w != 0.f) trow[(wy + dy - 1) * WW + wx + dx - 1] = f32_to_bf16(w);
+          }
+      }
+      __syncthreads();
+    }
+    // C. this stage's registers are free again: the loads of the tile DEPTH ahead
+    if (prefetch) tile_load(S, pa0, pb0);
+    // D. transposed blur of the tile: g[channel][pixel] = window^T (A, transposing read) x Tt^T (B, 16 contiguous bytes per lane)
+    f32x16_t gacc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gacc[cb][j] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NQ / 16; ++ks) {
+      const uint4 b = *reinterpret_cast<const uint4*>(ttb + pl * TP + (ks * 16 + 8 * hh) * 2);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const uint4 a = tr16(winb + cb * PLANE + ks * 16 * ROWB + trA, 4 * ROWB);
+        gacc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), gacc[cb], 0, 0, 0);
+      }
+    }
+    // E. LeakyReLU' from the sign word, bias sums, bf16, into the dO tile [ni][pixel][32 channels] the weight-gradient loop reads
+    {
+      const uint2 m64 = *reinterpret_cast<const uint2*>(maskb + pl * 8);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const unsigned mlo = (cb ? m64.y : m64.x) >> (4 * hh);     // bit 8 q4 + e of mlo = this lane's channel 8 q4 + 4 hh + e of the block
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gv = gacc[cb][4 * q4 + e];
+            v[e] = (mlo & (1u << (8 * q4 + e))) ? gv : gv * slope;
+            bsum[cb][4 * q4 + e] += v[e];
+          }
+          uint2 o;
+          o.x = pack_bf16x2(v[0], v[1]);
+          o.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(smem + (cb * 128 + pl) * ROWB + (8 * q4 + 4 * hh) * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    // F. the weight-gradient MFMAs of tfc_wgrad_c8_kernel
+    {
+      const unsigned char* hrow = halo0 + cur * HALO_BYTES + wave * pd.hw * 16 + trB;
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const uint4 b = tr16(hrow + kt * pd.hw * 16, 4 * 16);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const uint4 a = tr16(smem + ni * 128 * ROWB + kt * 16 * ROWB + trA, 4 * ROWB);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[ni], 0, 0, 0);
+        }
+      }
+    }
+    cur ^= 1;
+  };
+  // the workgroup's tiles in order; (tyb, txb): the tile being processed, (pyb, pxb): the tile DEPTH ahead
+  int txb = (t0 - wimg * tpi) % d.tiles_x, tyb = (t0 - wimg * tpi) / d.tiles_x;
+  int pxb = txb, pyb = tyb;
+  auto step = [&](int& xb, int& yb) { if (++xb == d.tiles_x) { xb = 0; ++yb; } };
+  if (t0 < t1) { tile_load(S0, pyb * TFC_TILE_H, pxb * TFC_TILE_W); step(pxb, pyb); }
+  if (DEPTH == 2 && t0 + 1 < t1) { tile_load(S1, pyb * TFC_TILE_H, pxb * TFC_TILE_W); step(pxb, pyb); }
+  for (int tl = t0; tl < t1; tl += DEPTH) {
+    body(S0, tyb * TFC_TILE_H, txb * TFC_TILE_W, tl + DEPTH < t1, pyb * TFC_TILE_H, pxb * TFC_TILE_W);
+    step(txb, tyb); step(pxb, pyb);
+    if (DEPTH == 2 && tl + 1 < t1) {
+      body(S1, tyb * TFC_TILE_H, txb * TFC_TILE_W, tl + 1 + DEPTH < t1, pyb * TFC_TILE_H, pxb * TFC_TILE_W);
+      step(txb, tyb); step(pxb, pyb);
+    }
+  }
+  if (rstats) {
+    // bias-gradient sums in a fixed order: the 32 lanes of a half-wave hold the same channels for different pixels -> butterfly over lane bits 0..4,
+    // the four waves meet in four LDS slots, 64 threads add the slots in wave order
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float v = bsum[cb][j];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+        if ((lane & 31) == 0) sbias[wave * 64 + cb * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh] = v;
+      }
+    __syncthreads();
+    if (tid < 64) rstats[(size_t)sp * 64 + tid] = ((sbias[tid] + sbias[64 + tid]) + sbias[128 + tid]) + sbias[192 + tid];
+  }
+  float4* ps = slab + ((size_t)sp * 4 + wave) * (2 * 4 * 64) + lane;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      ps[(ni * 4 + q4) * 64] = make_float4(acc[ni][4 * q4], acc[ni][4 * q4 + 1], acc[ni][4 * q4 + 2], acc[ni][4 * q4 + 3]);
+}
+
 // position = ((ky * 2 + ni) * 4 + q4) * 64 + lane of the 2048 float4 of a workgroup slab. A block owns 16 positions; its 16 slab-lanes take the slabs
 // sp = l, l + 16, ... ascending and meet in LDS in lane order: a fixed summation order and ONE owner per accumulator element (no atomics).
 __global__ void __launch_bounds__(256)
@@ -3085,29 +3377,35 @@ static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const voi
 thread_local int g_tfc_force_cfg = -1;                           // test hook (tfc_debug_set_igemm_config): -1 = heuristic; per thread
 thread_local long long g_tfc_launch_count = 0;
 
+// first-layer shape (8 padded input channels, 4 x 4 raster taps, <= 64 output channels, bias / scale / LeakyReLU epilogue only)?
+bool tfc_conv_c8_eligible(const TfcGather& d, int flags) {
+  return d.Cin_pad == 8 && d.nplanes == 1 && d.ph_n <= 1 && d.SS == 1 && d.OS == 1 && plane_pattern(d.plane[0]) == 1 && d.Nout <= 64 && d.Nout % 8 == 0 &&
+         (flags & ~(TFC_EP_BIAS | TFC_EP_LEAKY)) == 0;
+}
+hipError_t tfc_launch_conv_c8(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, const float* oscale, int flags,
+                              unsigned char* sign_mask, hipStream_t st) {
+  static int grid_cap = 0;
+  if (!grid_cap) {
+    int occ = 0, dev = 0, ncu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_conv_c8_kernel, 256, 0);
+    if (e != hipSuccess) return e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    grid_cap = (occ < 1 ? 1 : occ) * ncu;
+  }
+  const int nwork = d.nimg * d.tiles_y * d.tiles_x;
+  TFC_LAUNCH(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
+             (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork, sign_mask);
+  return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t launch_igemm_t(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias,
                                  float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st) {
   const int nb = tfc_nb32(d.Nout);
   const int fcfg = g_tfc_force_cfg < 0 ? -1 : (g_tfc_force_cfg & 15);     // bit 4 of the test hook selects the one-tile-per-workgroup kernel
   if constexpr (sizeof(T) == 2) {
-    // first-layer shape (8 padded input channels, 4 x 4 raster taps, <= 64 output channels, bias / scale epilogue only)
-    if (g_tfc_force_cfg < 0 && d.Cin_pad == 8 && d.nplanes == 1 && d.ph_n <= 1 && d.SS == 1 && d.OS == 1 && plane_pattern(d.plane[0]) == 1 &&
-        d.Nout <= 64 && d.Nout % 8 == 0 && (flags & ~(TFC_EP_BIAS | TFC_EP_LEAKY)) == 0) {
-      static int grid_cap = 0;
-      if (!grid_cap) {
-        int occ = 0, dev = 0, ncu = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_conv_c8_kernel, 256, 0);
-        if (e != hipSuccess) return e;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        grid_cap = (occ < 1 ? 1 : occ) * ncu;
-      }
-      const int nwork = d.nimg * d.tiles_y * d.tiles_x;
-      TFC_LAUNCH(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
-                         (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork);
-      return hipGetLastError();
-    }
+    if (g_tfc_force_cfg < 0 && tfc_conv_c8_eligible(d, flags)) return tfc_launch_conv_c8(d, in, wp, out, bias, oscale, flags, nullptr, st);
   }
 #ifdef TFC_PROBE_W64
   if constexpr (sizeof(T) == 2) {
@@ -3221,7 +3519,8 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
 }
 // fused first-block backward (tfc_wgrad_c8_fused_kernel): d = the TFC_OP_CONV pass-2 descriptor of the layer (8 padded input channels, 64 outputs)
 hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
-                                      void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real, hipStream_t st) {
+                                      void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real,
+                                      const unsigned char* sign_mask, hipStream_t st) {
   // wpi workgroups per image, each with `per` consecutive tiles of that image: about 512 workgroups in all (2 per CU), at most 2048 (32 KB of slab each)
   const int tpi = d.tiles_y * d.tiles_x;
   int wpi = 512 / d.nimg;
@@ -3231,8 +3530,16 @@ hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int 
   wpi = (tpi + per - 1) / per;
   const int ns = d.nimg * wpi;
   if (ns > 2048 || (rstats && (!part_ws || (long long)ns * 64 > (long long)TFC_PART_WS_FLOATS))) return hipErrorInvalidValue;
-  TFC_LAUNCH(tfc_wgrad_c8_fused_kernel, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)yact, y_pitch, (const bf16_t*)dyp, dyp_pitch, Ho, Wo,
-             (const bf16_t*)in, (float4*)slab, rstats ? part_ws : nullptr, slope, wpi, per);
+  const char* valu_env = getenv("TFC_FIRST_BWD_VALU");            // A/B knob (read per call: the tests compare the two forms in one process)
+  if (valu_env && atoi(valu_env) != 0 && yact)
+    TFC_LAUNCH(tfc_wgrad_c8_fused_kernel, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)yact, y_pitch, (const bf16_t*)dyp, dyp_pitch, Ho, Wo,
+               (const bf16_t*)in, (float4*)slab, rstats ? part_ws : nullptr, slope, wpi, per);
+  else if (sign_mask)                                             // transposed blur on the matrix core, signs from the forward pass's sign words
+    TFC_LAUNCH(tfc_wgrad_c8_fusedm_kernel<true>, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)yact, y_pitch, (const bf16_t*)dyp, dyp_pitch, Ho, Wo,
+               (const bf16_t*)in, (float4*)slab, rstats ? part_ws : nullptr, slope, wpi, per, sign_mask);
+  else
+    TFC_LAUNCH(tfc_wgrad_c8_fusedm_kernel<false>, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)yact, y_pitch, (const bf16_t*)dyp, dyp_pitch, Ho, Wo,
+               (const bf16_t*)in, (float4*)slab, rstats ? part_ws : nullptr, slope, wpi, per, sign_mask);
   TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(128), dim3(256), 0, st, (const float4*)slab, dwacc, ns, Nn_real, Cw_real);
   if (rstats) return tfc_launch_part_reduce(part_ws, rstats, d.nimg, wpi, 64, st);   // rstats[img][64] += the image's workgroup slots, in order
   return hipGetLastError();

@@ -198,7 +198,12 @@ class GeneratorCore:
             h = cur.H
             raw = new_act(N, h - 1, h - 1, cout, dt, dev)
             stats = ops.zeros_f32((N, cout, 2), dev) if normalize else None
-            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.packed[name]["fwd"], raw, stats=stats)
+            if i == 0 and save and not normalize and ops.first_block_bwd_supported(dt, cin, cout):
+                # the first convolution also leaves one sign bit per output value: all its fused backward (weight gradient only) reads of `raw`
+                ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev)
+                ops.conv_first_fwd(dt, cur, cin, cout, self.packed[name]["fwd"], raw, sign_mask=ctx.mask1)
+            else:
+                ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.packed[name]["fwd"], raw, stats=stats)
             if i < 5:
                 up = skip_of[i]
                 upc = cat[up].C - cout
@@ -311,7 +316,8 @@ class GeneratorCore:
                 # nothing but this weight gradient needs the 266 MB gradient of the first convolution's output: it is never written (igemm.hip:
                 # tfc_wgrad_c8_fused_kernel = tfc_act_bwd(mode 0, pool 2) + tfc_conv_wgrad in one kernel, same d_raw bits)
                 def _first_wgrad(din=din, raw=raw, g_cur=g_cur, cin=cin, cout=cout, key=key):
-                    self._ws = ops.first_block_bwd_wgrad(dt, din, raw, g_cur, cin, cout, grads[key], slope=0.2, accumulate=accumulate, ws=self._ws)
+                    self._ws = ops.first_block_bwd_wgrad(dt, din, raw, g_cur, cin, cout, grads[key], slope=0.2, accumulate=accumulate, ws=self._ws,
+                                                         sign_mask=getattr(ctx, "mask1", None))
                     if hook:
                         hook(key)
                 _on_side(dev, _first_wgrad, g_cur)
@@ -427,8 +433,13 @@ class DiscriminatorCore:
             raw = new_act(N, h - 1, h - 1, cout, dt, dev)
             # SN-conv + bias + LeakyReLU(0.2) in one kernel (P16:188-190): `raw` holds the ACTIVATED tensor; the backward's slope test
             # (y > 0) is the same on y = LeakyReLU(z) as on z, so act_bwd below keeps slope = 0.2 on this tensor
-            ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:],
-                         flags=ops.EP_LEAKY)
+            if bi == 0 and save and ops.first_block_bwd_supported(dt, cin, cout):
+                ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev)       # sign bits for the fused backward of block 1
+                ops.conv_first_fwd(dt, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:],
+                                   flags=ops.EP_LEAKY, sign_mask=ctx.mask1)
+            else:
+                ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:],
+                             flags=ops.EP_LEAKY)
             out = new_act(N, pooled(h - 1), pooled(h - 1), cout, dt, dev)
             ops.act_fwd(dt, raw, out, stats=None, slope=1.0, pool=2)
             ctx.ins.append(cur)
@@ -492,7 +503,8 @@ class DiscriminatorCore:
                 def _first_wgrad(i=i, cin=cin, cout=cout, xin=xin, raw=raw, g_cur=g_cur, gb_img=gb_img, u=u, v=v, sigma2=sigma2):
                     W = self.params[f"model.{i}.parametrizations.weight.original"]
                     gsn = torch.empty_like(W)
-                    wsh[0] = ops.first_block_bwd_wgrad(dt, xin, raw, g_cur, cin, cout, gsn, slope=0.2, ws=wsh[0], bias_sums=gb_img)
+                    wsh[0] = ops.first_block_bwd_wgrad(dt, xin, raw, g_cur, cin, cout, gsn, slope=0.2, ws=wsh[0], bias_sums=gb_img,
+                                                       sign_mask=getattr(ctx, "mask1", None))
                     gbias = grads[f"model.{i}.bias"]
                     if not accumulate:
                         gbias.zero_()

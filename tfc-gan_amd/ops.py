@@ -215,16 +215,26 @@ def first_block_bwd_supported(dt, Cin, Cout):
     return bool(lib().tfc_first_block_bwd_supported(dt, Cin, Cout))
 
 
-def first_block_bwd_wgrad(dt, x: View, y: View, dy_pooled: View, Cin, Cout, dw, slope=0.2, accumulate=False, ws=None, bias_sums=None):
-    """[BlurPool]^T -> LeakyReLU' -> weight (+ bias) gradient of the first block in one kernel: the gradient of the conv output is never written"""
+def conv_first_fwd(dt, x: View, Cin, Cout, packed, y: View, bias=None, oscale=None, flags=0, sign_mask=None):
+    """first convolution of a network (8 padded input channels -> 64) on the weights-stationary kernel; sign_mask: uint8 [N, H-1, W-1, 8] that receives
+    one bit per stored value (> 0) for the fused backward of the block"""
+    if bias is not None:
+        flags |= EP_BIAS
+    check(lib().tfc_conv_first_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, Cin, Cout, _p(packed), y.ptr, y.pitch, _p(bias), _p(oscale), flags,
+                                   _p(sign_mask)), "tfc_conv_first_fwd")
+
+
+def first_block_bwd_wgrad(dt, x: View, y: View, dy_pooled: View, Cin, Cout, dw, slope=0.2, accumulate=False, ws=None, bias_sums=None, sign_mask=None):
+    """[BlurPool]^T -> LeakyReLU' -> weight (+ bias) gradient of the first block in one kernel: the gradient of the conv output is never written.
+    sign_mask (from conv_first_fwd): read instead of the stored activation y (8 bytes per pixel instead of 128)"""
     nbytes = lib().tfc_conv_wgrad_ws_bytes(OP_CONV, Cin, Cout)
     if ws is None or ws.numel() * ws.element_size() < nbytes:
         nbig = lib().tfc_conv_wgrad_ws_bytes(OP_CONV, 1024, 512)
         ws = torch.zeros(max(nbytes, nbig), dtype=torch.uint8, device=x.t.device)
     assert dw.dtype == torch.float32 and dw.is_contiguous()
-    check(lib().tfc_first_block_bwd_wgrad(stream_ptr(), dt, x.ptr, x.pitch, y.ptr, y.pitch, dy_pooled.ptr, dy_pooled.pitch, x.N, x.H, x.W, Cin, Cout, slope,
-                                          _p(ws), _p(dw), 1 if accumulate else 0, _p(bias_sums), part_ws(x.t.device) if bias_sums is not None else None),
-          "tfc_first_block_bwd_wgrad")
+    check(lib().tfc_first_block_bwd_wgrad(stream_ptr(), dt, x.ptr, x.pitch, None if y is None else y.ptr, 0 if y is None else y.pitch, dy_pooled.ptr,
+                                          dy_pooled.pitch, x.N, x.H, x.W, Cin, Cout, slope, _p(ws), _p(dw), 1 if accumulate else 0, _p(bias_sums),
+                                          part_ws(x.t.device) if bias_sums is not None else None, _p(sign_mask)), "tfc_first_block_bwd_wgrad")
     return ws
 
 
