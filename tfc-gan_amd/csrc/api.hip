@@ -625,7 +625,7 @@ extern "C" int tfc_conv_wgrad(void* stream, int dt, int op, const void* x, int x
 // ---- fused first-block backward --------------------------------------------------------------------------------------------------------
 hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
                                       void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real,
-                                      const unsigned char* sign_mask, hipStream_t st);
+                                      const unsigned char* sign_mask, TfcWgradFin* fin, hipStream_t st);
 
 extern "C" int tfc_first_block_bwd_supported(int dt, int Cin, int Cout) { return dt == TFC_DT_BF16 && Cin > 0 && Cin <= 8 && Cout == 64 ? 1 : 0; }
 extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, int x_pitch, const void* y, int y_pitch, const void* dy_pooled, int dyp_pitch,
@@ -648,15 +648,12 @@ extern "C" int tfc_first_block_bwd_wgrad(void* stream, int dt, const void* x, in
   REQUIRE(d.plane[0].ntaps == 16 && d.plane[0].hh <= TFC_MAX_HH && d.plane[0].hw <= TFC_MAX_HW, "unexpected descriptor");
   const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;          // pooled size of the (H-1) x (W-1) activation
   {
-    // class 3, not 1: this launch also carries the (VALU-bound) transposed blur that used to be an elementwise pass of its own -- keeping it out of
-    // the weight-gradient class keeps that class comparable across rounds
+    // class 3, not 1: this launch also carries the transposed blur that used to be an elementwise pass of its own -- keeping it out of the
+    // weight-gradient class keeps that class comparable across rounds. The slab reduction writes the torch-layout gradient itself (no finish pass).
     ProfScope prof(3, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), st, TFC_OP_CONV, 2, N, H, W, Cin, Cout);
-    CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, part_ws, slope, Cout, Cin, sign_mask, st),
-              "tfc_first_block_bwd_wgrad");
-  }
-  {
-    ProfScope prof(2, 0.0, st, TFC_OP_CONV, 3, N, H, W, Cin, Cout);
-    CHECK_HIP(tfc_launch_wgrad_finish((float*)((char*)ws + kWgradSlabBytes), dw, Cout, Cin, wm.sn, wm.sc, accumulate, st), "tfc_first_block_bwd_wgrad finish");
+    TfcWgradFin fin{dw, wm.sn, wm.sc, accumulate, false};
+    CHECK_HIP(tfc_launch_first_block_bwd(d, y, y_pitch, dy_pooled, dyp_pitch, Ho, Wo, x, ws, (float*)((char*)ws + kWgradSlabBytes), bias_sums, part_ws, slope, Cout, Cin,
+                                         sign_mask, &fin, st), "tfc_first_block_bwd_wgrad");
   }
   return 0;
 }

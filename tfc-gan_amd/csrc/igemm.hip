@@ -2553,8 +2553,11 @@ tfc_wgrad_c8_fusedm_kernel(const TfcGather d, const bf16_t* __restrict__ yact, i
 
 // position = ((ky * 2 + ni) * 4 + q4) * 64 + lane of the 2048 float4 of a workgroup slab. A block owns 16 positions; its 16 slab-lanes take the slabs
 // sp = l, l + 16, ... ascending and meet in LDS in lane order: a fixed summation order and ONE owner per accumulator element (no atomics).
+// grad != nullptr: the sums go straight into the torch-layout gradient grad[n * sn + c * sc + ky * 4 + kx] (=/+=) and the accumulator is not touched
+// (one launch instead of reduce + tfc_wgrad_finish_kernel; the gradient is 64 x 8 x 16 floats)
 __global__ void __launch_bounds__(256)
-tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int Nn_real, int Cw_real) {
+tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nsplit, int Nn_real, int Cw_real, float* grad, long long sn, long long sc,
+                           int accumulate) {
   __shared__ float4 red[16][16];
   const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int pos = blockIdx.x * 16 + pl;
@@ -2576,7 +2579,14 @@ tfc_wgrad_c8_reduce_kernel(const float4* __restrict__ slab, float* acc, int nspl
   const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    if (n0 + e < Nn_real) acc[((size_t)(ky * 4 + kx) * Nn_real + n0 + e) * Cw_real + c] += sv[e];
+    if (n0 + e < Nn_real) {
+      if (grad) {
+        float* g = grad + (long long)(n0 + e) * sn + (long long)c * sc + ky * 4 + kx;
+        *g = accumulate ? *g + sv[e] : sv[e];
+      } else {
+        acc[((size_t)(ky * 4 + kx) * Nn_real + n0 + e) * Cw_real + c] += sv[e];
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3496,7 +3506,10 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
         d.plane[0].hh <= TFC_MAX_HH && d.plane[0].hw <= TFC_MAX_HW && (g_tfc_force_cfg < 0 || (g_tfc_force_cfg & 15) == 15)) {
       const int ns = ntiles < 512 ? ntiles : 512;                 // 2 workgroups per CU, 32 KB of slab each
       TFC_LAUNCH(tfc_wgrad_c8_kernel, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)dO, (const bf16_t*)in, slab, Nn_pad, ns);
-      TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(128), dim3(256), 0, st, slab, dwacc, ns, Nn_real, Cw_real);
+      const bool direct = fin && fin->grad;
+      TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(128), dim3(256), 0, st, slab, dwacc, ns, Nn_real, Cw_real, direct ? fin->grad : nullptr,
+                 direct ? fin->sn : 0, direct ? fin->sc : 0, direct ? fin->accumulate : 0);
+      if (direct) fin->done = true;
       return hipGetLastError();
     }
   }
@@ -3520,7 +3533,7 @@ static hipError_t launch_wgrad_t(const TfcGather& d, const void* dO, const void*
 // fused first-block backward (tfc_wgrad_c8_fused_kernel): d = the TFC_OP_CONV pass-2 descriptor of the layer (8 padded input channels, 64 outputs)
 hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int y_pitch, const void* dyp, int dyp_pitch, int Ho, int Wo, const void* in,
                                       void* slab, float* dwacc, float* rstats, float* part_ws, float slope, int Nn_real, int Cw_real,
-                                      const unsigned char* sign_mask, hipStream_t st) {
+                                      const unsigned char* sign_mask, TfcWgradFin* fin, hipStream_t st) {
   // wpi workgroups per image, each with `per` consecutive tiles of that image: about 512 workgroups in all (2 per CU), at most 2048 (32 KB of slab each)
   const int tpi = d.tiles_y * d.tiles_x;
   int wpi = 512 / d.nimg;
@@ -3540,7 +3553,9 @@ hipError_t tfc_launch_first_block_bwd(const TfcGather& d, const void* yact, int 
   else
     TFC_LAUNCH(tfc_wgrad_c8_fusedm_kernel<false>, dim3(ns), dim3(256), 0, st, d, (const bf16_t*)yact, y_pitch, (const bf16_t*)dyp, dyp_pitch, Ho, Wo,
                (const bf16_t*)in, (float4*)slab, rstats ? part_ws : nullptr, slope, wpi, per, sign_mask);
-  TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(128), dim3(256), 0, st, (const float4*)slab, dwacc, ns, Nn_real, Cw_real);
+  TFC_LAUNCH(tfc_wgrad_c8_reduce_kernel, dim3(128), dim3(256), 0, st, (const float4*)slab, dwacc, ns, Nn_real, Cw_real, fin->grad, fin->sn, fin->sc,
+             fin->accumulate);
+  fin->done = true;
   if (rstats) return tfc_launch_part_reduce(part_ws, rstats, d.nimg, wpi, 64, st);   // rstats[img][64] += the image's workgroup slots, in order
   return hipGetLastError();
 }
