@@ -72,7 +72,7 @@ def cpu_baseline(budget_s=8.0):
                       f"batch 4: 2 warm-up + {n4} timed steps in {dt4:.1f} s; batch 32 (value): 1 warm-up + 1 timed step in {dt32:.1f} s"}
 
 
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # written by scripts/pmc_traffic.py from the two --pmc passes of THIS command
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # written by scripts/pmc_traffic.py from the two --pmc passes of THIS command
 DOMINANT_KERNEL = "tfc_igemm2_kernel"
 PROF_EVERY = 4        # instrument every 4th timed step with hipEvents (see main)
 

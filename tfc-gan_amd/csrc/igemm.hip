@@ -967,7 +967,8 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4)
 tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* __restrict__ out,
-                   const float* __restrict__ bias, const float* __restrict__ oscale, int leaky, int NB32, int nwork, unsigned char* __restrict__ sign_mask) {
+                   const float* __restrict__ bias, const float* __restrict__ oscale, int leaky, int NB32, int nwork, unsigned char* __restrict__ sign_mask,
+                   int plain_store) {
   constexpr int P = TFC_LDS_P, PS = 16, MT = 2;
   constexpr int HB = TFC_MAX_HH * P * PS;                        // one halo buffer (4224 B)
   constexpr int ROWP = 64 * 2 + 16;                              // staged output tile: 64 channels per pixel row + pad
@@ -1055,7 +1056,9 @@ tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4
       const int a = a0 + (pix >> 4), b = b0 + (pix & 15);
       if (a < d.GH && b < d.GW && u * 8 < d.Nout) {
         const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * ROWP + u * 16);
-        store_stream16(out + ((size_t)(img * d.OH + a + d.OOY) * d.OW + b + d.OOX) * d.out_pitch + u * 8, v);
+        bf16_t* po = out + ((size_t)(img * d.OH + a + d.OOY) * d.OW + b + d.OOX) * d.out_pitch + u * 8;
+        if (plain_store) *reinterpret_cast<uint4*>(po) = v;         // (experiment knob TFC_C8_PLAIN: default-policy stores instead of streaming ones)
+        else store_stream16(po, v);
         if (sign_mask) {
           // one bit per stored value, (value > 0): all the first block's backward needs of this 266 MB tensor when only its weight / bias gradient is
           // wanted (tfc_wgrad_c8_fusedm_kernel reads 8 bytes per pixel instead of 128). Byte u of pixel (a, b) = channels 8u .. 8u+7.
@@ -3405,7 +3408,8 @@ hipError_t tfc_launch_conv_c8(const TfcGather& d, const void* in, const void* wp
   }
   const int nwork = d.nimg * d.tiles_y * d.tiles_x;
   TFC_LAUNCH(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
-             (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork, sign_mask);
+             (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork, sign_mask,
+             [] { const char* e = getenv("TFC_C8_PLAIN"); return e && atoi(e) != 0 ? 1 : 0; }());
   return hipGetLastError();
 }
 
