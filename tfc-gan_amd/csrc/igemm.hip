@@ -965,15 +965,29 @@ tfc_igemm2_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4*
 // BEFORE the current tile's stores are issued (vmcnt retires in order: a load issued behind stores would have to wait for them),
 // so nothing in the steady state ever waits for a store. Bound: the 266 MB output stream (HBM).
 // ---------------------------------------------------------------------------------------------------
+template <int LANE> __device__ __forceinline__ unsigned tfc_writelane(unsigned v, unsigned old) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(LANE));   // lane LANE of the result <- the wave-uniform v (one SGPR operand: constant bus)
+  return old;
+#else
+  (void)v; return old;
+#endif
+}
+// MASK: also leave one sign bit per stored value (value > 0) -- 8 bytes per pixel, all that the fused backward of the block reads of this 266 MB tensor
+// (tfc_wgrad_c8_fusedm_kernel). A lane of the accumulator holds ONE channel of 16 pixels, so the comparison of a register across the wave IS the sign
+// word: v_cmp writes a 64-bit lane mask = the 32 channels of this wave for two pixels; v_writelane files it under the pixel's lane, one 4-byte LDS
+// store per lane and tile, and 128 threads of the store pass write the tile's 1 KB of sign words. (Deriving the bits in the store pass -- unpack,
+// eight compares, a byte or a butterfly per unit -- cost 26-40 us per launch: the kernel lives at 128 VGPRs and four workgroups per CU.)
+template <bool MASK>
 __global__ void __launch_bounds__(256, 4)
 tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4* __restrict__ wp, bf16_t* __restrict__ out,
-                   const float* __restrict__ bias, const float* __restrict__ oscale, int leaky, int NB32, int nwork, unsigned char* __restrict__ sign_mask,
-                   int plain_store) {
+                   const float* __restrict__ bias, const float* __restrict__ oscale, int leaky, int NB32, int nwork, unsigned char* __restrict__ sign_mask) {
   constexpr int P = TFC_LDS_P, PS = 16, MT = 2;
   constexpr int HB = TFC_MAX_HH * P * PS;                        // one halo buffer (4224 B)
   constexpr int ROWP = 64 * 2 + 16;                              // staged output tile: 64 channels per pixel row + pad
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HB + 128 * ROWP];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HB + 128 * ROWP + (MASK ? 128 * 8 : 0)];
   unsigned char* stage = smem + 2 * HB;
+  unsigned* smask = reinterpret_cast<unsigned*>(smem + 2 * HB + 128 * ROWP);   // [128 pixels][2 channel halves]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1034,16 +1048,30 @@ tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4
         acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[s]), acc[mi], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
+    unsigned mw = 0;                                              // MASK: lane (mi * 32 + row) <- sign word of this wave's 32 channels for that pixel
+    tfc_static_for<0, MT>([&](auto mic) {
+      constexpr int mi = decltype(mic)::value;
+      tfc_static_for<0, 16>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
         const int ty = 2 * (wm * MT + mi) + (row & 1), tx = row >> 1;
         float v = acc[mi][j] * osc + bv;
         if (leaky) v = fmaxf(v, 0.2f * v);
-        *reinterpret_cast<bf16_t*>(stage + (ty * TFC_TILE_W + tx) * ROWP + n * 2) = f32_to_bf16(v);
-      }
+        const bf16_t hb = f32_to_bf16(v);
+        *reinterpret_cast<bf16_t*>(stage + (ty * TFC_TILE_W + tx) * ROWP + n * 2) = hb;
+        if constexpr (MASK) {
+          const unsigned long long bal = __ballot((short)hb > 0);  // bf16 is sign-magnitude: > 0 <=> the bits as a signed integer > 0
+          constexpr int r0 = (j & 3) + 8 * (j >> 2);               // the pixel rows of the two half-waves: r0 (lanes 0..31), r0 + 4 (lanes 32..63)
+          mw = tfc_writelane<mi * 32 + r0>((unsigned)bal, mw);
+          mw = tfc_writelane<mi * 32 + r0 + 4>((unsigned)(bal >> 32), mw);
+        }
+      });
+    });
+    if constexpr (MASK) {
+      const int mrow = lane & 31;
+      const int mty = 2 * (wm * MT + (lane >> 5)) + (mrow & 1), mtx = mrow >> 1;
+      smask[(mty * TFC_TILE_W + mtx) * 2 + wn] = mw;
+    }
     const bool has1 = (w + G) < nwork;
     if (has1 && hact) *reinterpret_cast<uint4*>(smem + ((k + 1) & 1) * HB + hoff) = hv;
     int nn_img = 0, nn_a0 = 0, nn_b0 = 0;
@@ -1056,19 +1084,14 @@ tfc_conv_c8_kernel(const TfcGather d, const bf16_t* __restrict__ in, const uint4
       const int a = a0 + (pix >> 4), b = b0 + (pix & 15);
       if (a < d.GH && b < d.GW && u * 8 < d.Nout) {
         const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * ROWP + u * 16);
-        bf16_t* po = out + ((size_t)(img * d.OH + a + d.OOY) * d.OW + b + d.OOX) * d.out_pitch + u * 8;
-        if (plain_store) *reinterpret_cast<uint4*>(po) = v;         // (experiment knob TFC_C8_PLAIN: default-policy stores instead of streaming ones)
-        else store_stream16(po, v);
-        if (sign_mask) {
-          // one bit per stored value, (value > 0): all the first block's backward needs of this 266 MB tensor when only its weight / bias gradient is
-          // wanted (tfc_wgrad_c8_fusedm_kernel reads 8 bytes per pixel instead of 128). Byte u of pixel (a, b) = channels 8u .. 8u+7.
-          float f[8];
-          unpack16<bf16_t>(v, f);
-          unsigned bits = 0;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bits |= (f[e] > 0.f ? 1u : 0u) << e;
-          sign_mask[((size_t)(img * d.OH + a) * d.OW + b) * 8 + u] = (unsigned char)bits;
-        }
+        store_stream16(out + ((size_t)(img * d.OH + a + d.OOY) * d.OW + b + d.OOX) * d.out_pitch + u * 8, v);
+      }
+    }
+    if constexpr (MASK) {
+      if (tid < 128) {
+        const int a = a0 + (tid >> 4), b = b0 + (tid & 15);
+        if (a < d.GH && b < d.GW)
+          *reinterpret_cast<uint2*>(sign_mask + ((size_t)(img * d.OH + a) * d.OW + b) * 8) = *reinterpret_cast<const uint2*>(smask + tid * 2);
       }
     }
     if (!has1) break;
@@ -3400,16 +3423,19 @@ hipError_t tfc_launch_conv_c8(const TfcGather& d, const void* in, const void* wp
   static int grid_cap = 0;
   if (!grid_cap) {
     int occ = 0, dev = 0, ncu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_conv_c8_kernel, 256, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tfc_conv_c8_kernel<true>, 256, 0);
     if (e != hipSuccess) return e;
     if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
     grid_cap = (occ < 1 ? 1 : occ) * ncu;
   }
   const int nwork = d.nimg * d.tiles_y * d.tiles_x;
-  TFC_LAUNCH(tfc_conv_c8_kernel, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
-             (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork, sign_mask,
-             [] { const char* e = getenv("TFC_C8_PLAIN"); return e && atoi(e) != 0 ? 1 : 0; }());
+  if (sign_mask)
+    TFC_LAUNCH(tfc_conv_c8_kernel<true>, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
+               (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork, sign_mask);
+  else
+    TFC_LAUNCH(tfc_conv_c8_kernel<false>, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
+               (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork, sign_mask);
   return hipGetLastError();
 }
 
