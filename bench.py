@@ -268,7 +268,7 @@ def main():
                                               "unit": "TFLOP/s", "calls": ig_n, "share_of_step_time": (ig_ms / 1e3 / nprof) / step_s},
                          "second_kernel": {"kernel": "tfc_wgrad_kernel family (incl. slab reduction)", "achieved": (wg_flop / 1e12) / (wg_ms / 1e3) if wg_ms > 0 else 0.0,
                                            "unit": "TFLOP/s", "launches": wg_n, "share_of_step_time": (wg_ms / 1e3 / nprof) / step_s},
-                         "fused_first_block_backward": {"kernel": "tfc_wgrad_c8_fused_kernel (VALU-bound transposed blur + first-layer weight gradient)",
+                         "fused_first_block_backward": {"kernel": "tfc_wgrad_c8_fusedm_kernel (transposed blur as a GEMM on the matrix core + first-layer weight gradient; sign words instead of the stored activation)",
                                                         "calls": fb_n, "avg_call_ms": fb_ms / max(fb_n, 1), "share_of_step_time": (fb_ms / 1e3 / nprof) / step_s}},
             "whole_step_tflops": T.TrainStep.STEP_GFLOP * value / 1e3,
             # stream time between "all buckets issued" and "all buckets arrived" in BucketReducer.finish(), summed over the generator's and the

@@ -33,9 +33,26 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP sources for gfx950 into tfc-gan_amd/libtfcgan_hip.so (cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 into tfc-gan_amd/libtfcgan_hip.so (cross-compiles without a GPU). Safe under `torch.distributed.run`:
+    ranks that find the library stale take a file lock, ONE of them compiles, the others wait and load its result."""
     if not force and not _stale():
         return SO_PATH
+    import fcntl
+    try:
+        lk = open(SO_PATH + ".lock", "w")
+    except OSError:                                               # read-only tree: nothing to coordinate with
+        return _build_locked(verbose)
+    with lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():                        # another rank built it while this one waited
+                return SO_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"

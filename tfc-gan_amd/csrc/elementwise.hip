@@ -901,8 +901,22 @@ __global__ void __launch_bounds__(1024) tfc_snb_vnorm_kernel(const SnBatch b, fl
   const int L = blockIdx.x, R = b.R[L], K = b.K[L];
   const int nz = (R + 31) / 32;
   const float* tp = b.t[L];
+  // this thread's columns k = tid, tid + 1024, ...: the first four stay in registers (K <= 4096 on the path), so the partials are read once; the z loop
+  // is unrolled so that its loads are in flight together (the adds stay in z order)
+  float tv[4] = {0.f, 0.f, 0.f, 0.f};
   float a = 0.f;
-  for (int k = threadIdx.x; k < K; k += 1024) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = threadIdx.x + i * 1024;
+    if (k < K) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int z = 0; z < nz; ++z) t += tp[(size_t)z * K + k];
+      tv[i] = t;
+      a += t * t;
+    }
+  }
+  for (int k = threadIdx.x + 4096; k < K; k += 1024) {
     float t = 0.f;
     for (int z = 0; z < nz; ++z) t += tp[(size_t)z * K + k];
     a += t * t;
@@ -914,7 +928,16 @@ __global__ void __launch_bounds__(1024) tfc_snb_vnorm_kernel(const SnBatch b, fl
 #pragma unroll
   for (int i = 0; i < 16; ++i) tot += red[i];
   const float inv = 1.f / fmaxf(sqrtf(tot), eps);
-  for (int k = threadIdx.x; k < K; k += 1024) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = threadIdx.x + i * 1024;
+    if (k < K) {
+      const float x = tv[i] * inv;
+      b.v[L][k] = x;
+      if (b.vs[L]) b.vs[L][k] = x;
+    }
+  }
+  for (int k = threadIdx.x + 4096; k < K; k += 1024) {
     float t = 0.f;
     for (int z = 0; z < nz; ++z) t += tp[(size_t)z * K + k];
     const float x = t * inv;
