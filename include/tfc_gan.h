@@ -78,6 +78,13 @@ int tfc_conv_fwd(void* stream, int dt, int op, const void* x, int x_pitch, int N
  * the block needs of y when only its weight / bias gradient is wanted (tfc_first_block_bwd_wgrad reads 8 bytes per pixel instead of 128). */
 int tfc_conv_first_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const void* packed, void* y, int y_pitch,
                        const float* bias, const float* oscale, int flags, uint8_t* sign_mask);
+/* the whole first block forward in ONE kernel: BlurPool(stride 2)(LeakyReLU(slope)(oscale * conv(x) + bias)) -> out [N][Ho][Wo] (out_pitch), Ho = (H-2)/2+1,
+ * for discriminator_block(2 * channels, 64) (P16:187-196; act_after_rounding = 0: the activation runs before the bf16 rounding, as in the conv epilogue of
+ * the unfused chain) and UNetDown(channels, 64, normalize=False) (P16:140; act_after_rounding = 1: the raw conv output is rounded, the activation runs in
+ * fp32 inside the pooling). The 266 MB conv output is never written; sign_mask (nullable) receives its sign words as tfc_conv_first_fwd would leave them.
+ * Same numbers as tfc_conv_first_fwd + tfc_act_fwd(pool = 2) up to the fp32 summation order of the 16 blur taps (<= 1 bf16 ulp on rare elements). */
+int tfc_first_block_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const void* packed, const float* bias,
+                        const float* oscale, float slope, int act_after_rounding, void* out, int out_pitch, uint8_t* sign_mask);
 /* ---- PatchGAN head forward, P16:201-202: ZeroPad2d((1,0,1,0)) + Conv2d(C,1,k4,p1,no bias) as a wave-per-pixel dot product
  * (w: torch-layout fp32 [1][C][4][4], y: [N][H][W][y_pitch] channel 0). Same result as tfc_conv_fwd(TFC_OP_PADCONV, Cout=1). */
 int tfc_patchgan_head_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int C, const float* w,

@@ -27,3 +27,7 @@ print("first_fwd, no mask     :", t(lambda: ops.conv_first_fwd(dt, x, 6, 64, pk,
 print("first_fwd, sign words  :", t(lambda: ops.conv_first_fwd(dt, x, 6, 64, pk, raw, bias=bias, flags=ops.EP_LEAKY, sign_mask=mask)))
 out = ops.new_act(N, 128, 128, 64, dt, DEV)
 print("blur-pool               :", t(lambda: ops.act_fwd(dt, raw, out, stats=None, slope=1.0, pool=2)))
+osc = torch.tensor([0.7], device=DEV)
+print("fused first block (D)   :", t(lambda: ops.first_block_fwd(dt, x, 6, 64, pk, out, bias=bias, oscale=osc, slope=0.2, sign_mask=mask)))
+print("fused first block (D, no mask):", t(lambda: ops.first_block_fwd(dt, x, 6, 64, pk, out, bias=bias, oscale=osc, slope=0.2)))
+print("fused first block (G)   :", t(lambda: ops.first_block_fwd(dt, x, 6, 64, pk, out, slope=0.2, act_after_rounding=True, sign_mask=mask)))

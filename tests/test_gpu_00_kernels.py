@@ -308,6 +308,45 @@ def test_fused_first_block_backward_equals_unfused_chain(N, S, Cin, disc, valu, 
         assert torch.equal(dwa, dwb) and torch.equal(ra, rb2)
 
 
+@pytest.mark.parametrize("N,S,Cin,gform", [(2, 256, 6, False), (2, 256, 3, True), (3, 70, 6, False), (1, 41, 3, True), (2, 130, 6, False), (1, 18, 3, True), (1, 32, 6, False), (2, 34, 3, True),
+                                               (1, 62, 6, True)])
+def test_fused_first_block_forward_equals_unfused_chain(N, S, Cin, gform):
+    """round 3: conv -> (+bias, x 1/sigma) -> LeakyReLU -> BlurPool(stride 2) of the first block in ONE kernel (tfc_first_block_fwd: the 266 MB conv output is
+    never written, the BlurPool runs as a GEMM against the tile's tap matrix on the matrix core) against the chain it replaces, tfc_conv_first_fwd +
+    tfc_act_fwd(pool = 2). Both forms: D (activation before the bf16 rounding) and G (raw output rounded, activation in fp32 inside the pooling:
+    leaky(y) = max(y, 0) + 0.2 min(y, 0), both parts blurred separately). The conv values are the same bits (same MFMA order), the 16 exact tap products are
+    added in another order: the pooled outputs may differ by one bf16 ulp on rare elements; the sign words must be IDENTICAL. Sizes: full (ragged last tiles
+    in both directions: Wo = 128 = 8 x 15 + 8), odd sizes whose last pooled row / column uses the reflect aliases -- including those where that row (S = 70, 18) or column (S = 32, 62) is the FIRST
+    of its tile, whose alias lies in front of the tile's usual conv window --, a plane smaller than one tile."""
+    dt = DT_BF16
+    H = S - 1
+    Po = (H - 1) // 2 + 1
+    xv = to_view(q(rnd((N, Cin, S, S), 31), dt), dt)
+    w = rnd((64, Cin, 4, 4), 32, 0.3).to(DEV)
+    pk = ops.pack_weight(dt, ops.OP_CONV, 0, w, Cin, 64)
+    bias = None if gform else rnd((64,), 33, 0.3).to(DEV)
+    osc = None if gform else torch.tensor([0.61], device=DEV)
+    raw = ops.new_act(N, H, H, 64, dt, DEV)
+    m0 = torch.zeros((N, H, H, 8), dtype=torch.uint8, device=DEV)
+    ops.conv_first_fwd(dt, xv, Cin, 64, pk, raw, bias=bias, oscale=osc, flags=0 if gform else ops.EP_LEAKY, sign_mask=m0)
+    want = ops.new_act(N, Po, Po, 64, dt, DEV)
+    ops.act_fwd(dt, raw, want, stats=None, slope=0.2 if gform else 1.0, pool=2)
+    wide = torch.full((N, Po, Po, 128), 7.0, dtype=torch.bfloat16, device=DEV)          # the generator writes into a channel window of a concat buffer
+    got = View(wide, 64, 64)
+    m1 = torch.zeros((N, H, H, 8), dtype=torch.uint8, device=DEV)
+    ops.first_block_fwd(dt, xv, Cin, 64, pk, got, bias=bias, oscale=osc, slope=0.2, act_after_rounding=gform, sign_mask=m1)
+    torch.cuda.synchronize()
+    assert torch.equal(m0, m1), int((m0 != m1).sum())
+    assert (wide[..., :64] == 7.0).all()                                                # the neighbouring window is untouched
+    a, b = wide[..., 64:].float(), want.t.float()
+    err = (a - b).abs()
+    scale = b.abs().clamp_min(1e-3 * b.abs().max().item())
+    assert (err <= 2.0 ** -7 * scale).all(), (err / scale).max().item()               # <= 1 bf16 ulp
+    frac = (err > 0).float().mean().item()
+    print(f"  elements that differ: {frac:.2e}")
+    assert frac <= 2e-2, frac
+
+
 def test_planned_pack_equals_single_pack():
     """tfc_conv_pack_planned (one launch for every operand stream of a network; single-slot taps take a scan-free path) writes the same bytes
     as tfc_conv_pack, for every op and pass of the path -- plain, flipped (dgrad), phase-split (transposed conv), collapsed (upsample head), 3x3"""

@@ -144,6 +144,7 @@ PROTOTYPES = {
     "tfc_first_block_bwd_supported": (_i, [_i, _i, _i]),
     "tfc_first_block_bwd_wgrad": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "tfc_conv_first_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "tfc_first_block_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _i, _vp]),
     "tfc_resize_plan_bytes": (_sz, [_i, _i, _i]),
     "tfc_resize_plan_build": (_i, [_i, _i, _i, _vp]),
     "tfc_pair_resize_ws_bytes": (_sz, [_i, _i, _i]),

@@ -38,6 +38,8 @@ int tfc_nb32_padded(int nout);
 size_t tfc_packed_bytes(const TfcGather& d, int es);
 hipError_t tfc_launch_pack(int dt, const TfcGather& d, const float* w, const float* scale, void* wp, int Nreal, int Creal, long long sn, long long sc, hipStream_t st);
 hipError_t tfc_launch_igemm(int dt, const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, float* stats, float* part_ws, float* out_nchw, const float* oscale, int flags, hipStream_t st);
+hipError_t tfc_launch_first_block_fwd(const void* in, int N, int IH, int IW, const void* wp, const float* bias, const float* oscale, float slope, int gform,
+                                      void* out, int o_pitch, unsigned char* sign_mask, hipStream_t st);
 bool tfc_conv_c8_eligible(const TfcGather& d, int flags);
 hipError_t tfc_launch_conv_c8(const TfcGather& d, const void* in, const void* wp, void* out, const float* bias, const float* oscale, int flags,
                               unsigned char* sign_mask, hipStream_t st);
@@ -468,6 +470,22 @@ extern "C" int tfc_conv_first_fwd(void* stream, int dt, const void* x, int x_pit
   REQUIRE(tfc_conv_c8_eligible(d, flags), "unexpected descriptor");
   ProfScope prof(0, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), (hipStream_t)stream, TFC_OP_CONV, 0, N, H, W, Cin, Cout);
   CHECK_HIP(tfc_launch_conv_c8(d, x, packed, y, bias, oscale, flags, sign_mask, (hipStream_t)stream), "tfc_conv_first_fwd");
+  return 0;
+}
+
+extern "C" int tfc_first_block_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, int W, int Cin, int Cout, const void* packed, const float* bias,
+                                   const float* oscale, float slope, int act_after_rounding, void* out, int out_pitch, uint8_t* sign_mask) {
+  REQUIRE(dt == TFC_DT_BF16 && tfc_first_block_bwd_supported(dt, Cin, Cout), "tfc_first_block_fwd: bf16, Cin <= 8, Cout == 64");
+  if (int e = check_common(dt, TFC_OP_CONV, N, H, W, Cin, Cout)) return e;
+  if (int e = check_ptr16(x, "x")) return e;
+  if (int e = check_ptr16(packed, "packed")) return e;
+  REQUIRE(out && (((uintptr_t)out) & 7) == 0 && out_pitch >= 64 && out_pitch % 4 == 0, "out must be 8-byte aligned with pitch >= 64 and a multiple of 4");
+  REQUIRE(x_pitch == 8 && H >= 6 && W >= 6, "x pitch %d (must be 8); the reflect padding of the pooling needs a 5 x 5 convolution output at least", x_pitch);
+  REQUIRE(!sign_mask || (((uintptr_t)sign_mask) & 7) == 0, "sign_mask must be 8-byte aligned");
+  // 2 x (the convolution on the 1.33x overlapping regions) is what the kernel executes; the algorithmic work of the block is the convolution's
+  ProfScope prof(0, conv_flop(TFC_OP_CONV, N, H, W, Cin, Cout), (hipStream_t)stream, TFC_OP_CONV, 0, N, H, W, Cin, Cout);
+  CHECK_HIP(tfc_launch_first_block_fwd(x, N, H, W, packed, bias, oscale, slope, act_after_rounding, out, out_pitch, sign_mask, (hipStream_t)stream),
+            "tfc_first_block_fwd");
   return 0;
 }
 

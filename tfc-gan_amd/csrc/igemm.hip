@@ -3413,6 +3413,260 @@ static hipError_t launch_igemm_cfg(const TfcGather& d, const void* in, const voi
 thread_local int g_tfc_force_cfg = -1;                           // test hook (tfc_debug_set_igemm_config): -1 = heuristic; per thread
 thread_local long long g_tfc_launch_count = 0;
 
+// ---------------------------------------------------------------------------------------------------
+// First block, FORWARD, fused (round 3): conv(8 padded channels -> 64, k4 s1 p1) -> [+bias, x 1/sigma] -> LeakyReLU(0.2) -> BlurPool(stride 2) in one
+// kernel. The unfused pair (tfc_conv_c8_kernel, tfc_act_pool2_fwd_kernel) writes the 255 x 255 x 64 conv output (266 MB at batch 32) and reads it
+// back -- 532 MB of HBM traffic for a 67 MB result whose backward needs only the SIGN of that tensor (sign words, 16.6 MB). Here it never exists:
+//   * tile = 4 x 15 pooled pixels; their 10 x 32 conv pixels (5 row pairs x 2 column halves = 10 MFMA M-subtiles) are computed from a 13 x 35 input halo
+//     with the weights-stationary fragments of tfc_conv_c8_kernel (wave (wm, wn): 5 subtiles x 32 channels), rounded to bf16 exactly where the unfused
+//     chain stores them, and staged in LDS as two 32-channel planes [conv pixel][32] of 64-byte rows;
+//   * the BlurPool is LINEAR: pooled[p][c] = sum_k P[p][k] * y[k][c] with P = products of [1,3,3,1]/8 taps (reflect aliases merged; exact in bf16).
+//     A block of 2 pooled rows x 16 columns (32 = one MFMA N extent) depends on 6 conv rows x 32 columns = 192 positions: 12 MFMAs 32x32x16 per
+//     (block, 32-channel plane), one such pair per wave; the plane is the A operand through the transposing LDS read, P rows are 16-byte reads;
+//   * form D (discriminator block 1: LeakyReLU runs BEFORE the bf16 rounding, in the conv epilogue) blurs the stored bf16 activation; form G (generator
+//     down1: the raw conv output is rounded, LeakyReLU runs in fp32 inside the pooling pass) uses leaky(y) = max(y, 0) + 0.2 min(y, 0): both parts are
+//     bf16-exact (v_pk_max_i16 / v_pk_min_i16 on the sign-magnitude bits), blurred separately and combined in fp32 -- the same numbers as the fp32 blur of
+//     the unfused kernel up to the order of <= 16 exact-product additions;
+//   * sign words of the would-be-stored tensor leave through the accumulator comparison (v_cmp lane mask -> v_writelane), as in tfc_conv_c8_kernel<true>.
+// Each conv pixel is computed by the one or two tiles that need it (1.33x the conv MFMAs: the layer has 25.6 GFLOP, the matrix cores idle anyway).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pk_max0(unsigned w) {          // per 16-bit half: max(x, 0) as signed integers (v_pk_max_i16)
+  const s16x2_t z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, w), z));
+}
+template <bool GFORM>
+__global__ void __launch_bounds__(256, 2)
+tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const uint4* __restrict__ wp, int NB32, const float* __restrict__ bias,
+                           const float* __restrict__ oscale, float slope, bf16_t* __restrict__ out, int o_pitch, int Ho, int Wo,
+                           unsigned char* __restrict__ sign_mask, int nimg, int tiles_y, int tiles_x, int per) {
+  constexpr int P = 40, PS = 16;                                 // halo row pitch (pixels; == 8 mod 16: conflict-free fragment reads), bytes per halo pixel
+  constexpr int HHH = 13, HHW = 35;                              // input halo of the 10 x 32 conv region
+  constexpr int HB = HHH * P * PS;                               // 8320
+  constexpr int NK = 320, PLANE = NK * 64;                       // conv pixels of a tile; one 32-channel plane [k][32 ch]
+  constexpr int PP = 400, PB = 32 * PP;                          // tap matrix of a block: [32 pooled px][192 k] bf16, 400-byte rows (conflict-free 16-byte reads)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HB + 2 * PLANE + 2 * PB + NK * 8];
+  unsigned char* planes = smem + HB;
+  unsigned char* pmat = planes + 2 * PLANE;
+  unsigned* smask = reinterpret_cast<unsigned*>(pmat + 2 * PB);  // [320 conv px][2 channel halves]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, r = lane & 31;
+  const int CH = IH - 1, CW = IW - 1;                             // conv output size
+
+  uint4 bw[8];                                                   // this wave's 32 output channels x K = 128, for the whole launch
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bw[s] = wp[((size_t)s * NB32 + wn) * 64 + lane];
+  const int n = wn * 32 + r;
+  const float bv = bias ? bias[n] : 0.f;
+  const float osc = oscale ? *oscale : 1.f;
+
+  const int tpi = tiles_y * tiles_x;
+  const int ntiles = nimg * tpi;
+  const int t0 = blockIdx.x * per, t1 = (t0 + per) < ntiles ? (t0 + per) : ntiles;
+  if (t0 >= t1) return;
+  // halo staging: 13 x 35 pixels of 16 bytes, two per thread
+  int hy_[2], hx_[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int idx = tid + i * 256; hy_[i] = idx / HHW; hx_[i] = idx - hy_[i] * HHW; }
+  uint4 hv[2];
+  // conv row / column of region pixel (0, 0): 2 oy0 - 1 -- one less when the tile's FIRST pooled row (column) is the image's last one and the conv size is
+  // odd: its tap 2 oy + 2 = CH + 1 then reflects to CH - 3 = 2 oy0 - 2, in front of the usual origin (the rows behind are unused in that tile)
+  auto origin = [&](int o0, int Lo, int L) { return 2 * o0 - 1 - ((o0 == Lo - 1 && L == 2 * o0 + 1) ? 1 : 0); };
+  auto halo_load = [&](int tl) {
+    const int img = tl / tpi, rem = tl - img * tpi;
+    const int tyb = rem / tiles_x, txb = rem - tyb * tiles_x;
+    const int y0 = origin(4 * tyb, Ho, CH) - 1, x0 = origin(15 * txb, Wo, CW) - 1;   // input row / column of halo pixel (0, 0): conv row c reads input rows from c - 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      hv[i] = make_uint4(0, 0, 0, 0);
+      const int y = y0 + hy_[i], x = x0 + hx_[i];
+      if (hy_[i] < HHH && y >= 0 && y < IH && x >= 0 && x < IW) hv[i] = *reinterpret_cast<const uint4*>(in + ((size_t)(img * IH + y) * IW + x) * 8);
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (hy_[i] < HHH) *reinterpret_cast<uint4*>(smem + (hy_[i] * P + hx_[i]) * PS) = hv[i];
+  };
+  auto refl = [](int v, int L) { return v < 0 ? -v : (v >= L ? 2 * L - 2 - v : v); };
+  // first region row of the 6-row K window of block b (pooled rows oy0 + 2b, + 1): the smallest conv row its valid pooled rows touch (reflect aliases
+  // included), at most 4 so that the window stays inside the 10 region rows
+  auto win_start = [&](int b, int oy0, int cr0) {
+    int lo = 1 << 30;
+    for (int pr = 0; pr < 2; ++pr) {
+      const int oy = oy0 + 2 * b + pr;
+      if (oy >= Ho) continue;
+      for (int i = 0; i < 4; ++i) { const int y = refl(2 * oy - 1 + i, CH); lo = y < lo ? y : lo; }
+    }
+    const int w = lo == (1 << 30) ? 4 * b : lo - cr0;
+    return w < 0 ? 0 : (w > 4 ? 4 : w);
+  };
+  // the tap matrix of block b (pooled rows 2b, 2b + 1 of the tile): thread p < 32 owns pooled pixel p = pr * 16 + pc
+  auto pmat_build = [&](int b, int oy0, int ox0) {
+    unsigned char* pm = pmat + b * PB;
+    for (int i = tid; i < PB / 16; i += 256) *reinterpret_cast<uint4*>(pm + i * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (tid < 32) {
+      const int pr = tid >> 4, pc = tid & 15;
+      const int oy = oy0 + 2 * b + pr, ox = ox0 + pc;
+      if (pc < 15 && oy < Ho && ox < Wo) {
+        bf16_t* row = reinterpret_cast<bf16_t*>(pm + tid * PP);
+        const int rg0 = origin(oy0, Ho, CH);
+        const int cr0 = rg0 + win_start(b, oy0, rg0), cc0 = origin(ox0, Wo, CW);   // conv row / column of k = 0 of this block
+        for (int i = 0; i < 4; ++i) {
+          const int y = refl(2 * oy - 1 + i, CH);
+          const int rr = y - cr0;
+          for (int j = 0; j < 4; ++j) {
+            const int x = refl(2 * ox - 1 + j, CW);
+            const int cc = x - cc0;
+            if (rr >= 0 && rr < 6 && cc >= 0 && cc < 32) {
+              const float w = ((i == 0 || i == 3) ? 0.125f : 0.375f) * ((j == 0 || j == 3) ? 0.125f : 0.375f);
+              bf16_t* e = row + rr * 32 + cc;
+              *e = f32_to_bf16(bf16_to_f32(*e) + w);             // reflect aliases merge; every partial sum is a multiple of 1/64 <= 1: exact
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  };
+  int key_y[2] = {-(1 << 30), -(1 << 30)}, key_x = -(1 << 30);           // border class the two tap matrices were built for
+
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, pq = li & 3;
+  const int trA = (8 * hk + q) * 64 + cb16 * 32 + pq * 8;
+  auto tr16 = [&](const unsigned char* p0) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + 4 * 64));
+    uint4 o;
+    o.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    o.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    o.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    o.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return o;
+  };
+
+  halo_load(t0);
+  halo_store();
+  __syncthreads();
+  for (int tl = t0; tl < t1; ++tl) {
+    const int img = tl / tpi, rem = tl - img * tpi;
+    const int tyb = rem / tiles_x, txb = rem - tyb * tiles_x;
+    const int oy0 = 4 * tyb, ox0 = 15 * txb;
+    const bool more = tl + 1 < t1;
+    if (more) halo_load(tl + 1);                                  // into registers; the LDS halo is rewritten behind the conv phase
+    // ---- 1. convolution of the 10 x 32 region: subtile m = (row pair rp = m >> 1, column half m & 1); wave (wm, wn): m = 5 wm .. 5 wm + 4 ----
+    f32x16_t acc[5];
+#pragma unroll
+    for (int mi = 0; mi < 5; ++mi)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 5; ++mi) {
+      const int m = 5 * wm + mi;
+      const unsigned char* buf = smem + ((2 * (m >> 1) + (r & 1)) * P + 16 * (m & 1) + (r >> 1)) * PS + h * PS;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const uint4 a = *reinterpret_cast<const uint4*>(buf + ((s >> 1) * P + 2 * (s & 1)) * PS);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[s]), acc[mi], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                              // halo consumed
+    if (more) halo_store();
+    // ---- 2. epilogue: the value the unfused chain would store (bf16), into the planes; its sign into the sign words ----
+    tfc_static_for<0, 5>([&](auto mic) {
+      constexpr int mi = decltype(mic)::value;
+      const int m = 5 * wm + mi;
+      unsigned mw = 0;
+      tfc_static_for<0, 16>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+        const int k = (2 * (m >> 1) + (row & 1)) * 32 + 16 * (m & 1) + (row >> 1);
+        float v = acc[mi][j] * osc + bv;
+        if (!GFORM) v = fmaxf(v, slope * v);                       // form D: LeakyReLU before the rounding (conv epilogue of the unfused chain)
+        const bf16_t hb = f32_to_bf16(v);
+        *reinterpret_cast<bf16_t*>(planes + wn * PLANE + k * 64 + r * 2) = hb;
+        const unsigned long long bal = __ballot((short)hb > 0);
+        constexpr int r0 = (j & 3) + 8 * (j >> 2);
+        mw = tfc_writelane<r0>((unsigned)bal, mw);
+        mw = tfc_writelane<r0 + 4>((unsigned)(bal >> 32), mw);
+      });
+      if (lane < 32) {                                             // lane = pixel row of subtile m
+        const int k = (2 * (m >> 1) + (lane & 1)) * 32 + 16 * (m & 1) + (lane >> 1);
+        smask[k * 2 + wn] = mw;
+      }
+    });
+    // the tap matrices of this tile (rebuilt only when the border class of a block changes)
+    {
+      const int kx = (ox0 == 0 || 2 * (ox0 + 15) + 1 >= CW) ? ox0 : -1;
+      bool rb[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oyb = oy0 + 2 * b;
+        const int ky = (oyb == 0 || 2 * (oyb + 1) + 2 >= CH || oyb + 1 >= Ho) ? oyb : -1;
+        rb[b] = ky != key_y[b] || kx != key_x;
+        key_y[b] = ky;
+      }
+      key_x = kx;
+      if (rb[0]) pmat_build(0, oy0, ox0);
+      if (rb[1]) pmat_build(1, oy0, ox0);
+    }
+    __syncthreads();                                              // planes, sign words (and tap matrices) visible
+    // ---- 3. sign words of the conv pixels this tile owns: region rows 1..8, columns 1..30 ----
+    if (sign_mask && tid < 240) {
+      const int y = 2 * oy0 + tid / 30, x = 2 * ox0 + tid % 30;    // the tile owns conv rows 2 oy0 .. + 7, columns 2 ox0 .. + 29
+      const int rr = y - origin(oy0, Ho, CH), cc = x - origin(ox0, Wo, CW);
+      if (y < CH && x < CW && rr < 10 && cc < 32)
+        *reinterpret_cast<uint2*>(sign_mask + ((size_t)(img * CH + y) * CW + x) * 8) = *reinterpret_cast<const uint2*>(smask + (rr * 32 + cc) * 2);
+    }
+    // ---- 4. BlurPool as a GEMM: wave = (block b, 32-channel plane cb) ----
+    {
+      const int b = wave >> 1, cb = wave & 1;
+      f32x16_t gp, gn;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { gp[j] = 0.f; gn[j] = 0.f; }
+      const unsigned char* pa = planes + cb * PLANE + (32 * win_start(b, oy0, origin(oy0, Ho, CH))) * 64 + trA;
+      const unsigned char* pb = pmat + b * PB + r * PP + 8 * h * 2;
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) {
+        const uint4 a = tr16(pa + ks * 16 * 64);
+        const uint4 bm = *reinterpret_cast<const uint4*>(pb + ks * 32);
+        if constexpr (GFORM) {
+          uint4 ap, an;                                            // max(y, 0) and min(y, 0) on the sign-magnitude bits of the bf16 pairs
+          ap.x = pk_max0(a.x);
+          ap.y = pk_max0(a.y);
+          ap.z = pk_max0(a.z);
+          ap.w = pk_max0(a.w);
+          an.x = a.x ^ ap.x; an.y = a.y ^ ap.y; an.z = a.z ^ ap.z; an.w = a.w ^ ap.w;      // y = y+ or y-: the other part is all-zero bits
+          gp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ap), __builtin_bit_cast(bf16x8_t, bm), gp, 0, 0, 0);
+          gn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, an), __builtin_bit_cast(bf16x8_t, bm), gn, 0, 0, 0);
+        } else {
+          gp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bm), gp, 0, 0, 0);
+        }
+      }
+      // lane (pooled pixel r of the block, half h): 16 channels {8 q4 + 4 h + e} of plane cb
+      const int pr = r >> 4, pc = r & 15;
+      const int oy = oy0 + 2 * b + pr, ox = ox0 + pc;
+      if (pc < 15 && oy < Ho && ox < Wo) {
+        bf16_t* po = out + ((size_t)(img * Ho + oy) * Wo + ox) * o_pitch + cb * 32 + 4 * h;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = GFORM ? gp[4 * q4 + e] + slope * gn[4 * q4 + e] : gp[4 * q4 + e];
+          uint2 o;
+          o.x = pack_bf16x2(v[0], v[1]);
+          o.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(po + 8 * q4) = o;
+        }
+      }
+    }
+    __syncthreads();                                              // planes / sign words free for the next tile
+  }
+}
+
 // first-layer shape (8 padded input channels, 4 x 4 raster taps, <= 64 output channels, bias / scale / LeakyReLU epilogue only)?
 bool tfc_conv_c8_eligible(const TfcGather& d, int flags) {
   return d.Cin_pad == 8 && d.nplanes == 1 && d.ph_n <= 1 && d.SS == 1 && d.OS == 1 && plane_pattern(d.plane[0]) == 1 && d.Nout <= 64 && d.Nout % 8 == 0 &&
@@ -3436,6 +3690,26 @@ hipError_t tfc_launch_conv_c8(const TfcGather& d, const void* in, const void* wp
   else
     TFC_LAUNCH(tfc_conv_c8_kernel<false>, dim3(nwork < grid_cap ? nwork : grid_cap), dim3(256), 0, st, d, (const bf16_t*)in, (const uint4*)wp,
                (bf16_t*)out, (flags & TFC_EP_BIAS) ? bias : nullptr, oscale, (flags & TFC_EP_LEAKY) ? 1 : 0, tfc_nb32_padded(d.Nout), nwork, sign_mask);
+  return hipGetLastError();
+}
+
+// fused first block forward: x NHWC8 [N][IH][IW][8] -> pooled [N][Ho][Wo] (o_pitch); gform: LeakyReLU after the bf16 rounding of the raw conv output
+hipError_t tfc_launch_first_block_fwd(const void* in, int N, int IH, int IW, const void* wp, const float* bias, const float* oscale, float slope, int gform,
+                                      void* out, int o_pitch, unsigned char* sign_mask, hipStream_t st) {
+  const int CH = IH - 1, CW = IW - 1;
+  const int Ho = (CH - 1) / 2 + 1, Wo = (CW - 1) / 2 + 1;
+  const int tiles_y = (Ho + 3) / 4, tiles_x = (Wo + 14) / 15;
+  const int ntiles = N * tiles_y * tiles_x;
+  int nwg = 2 * tfc_num_cus();
+  if (nwg > ntiles) nwg = ntiles;
+  const int per = (ntiles + nwg - 1) / nwg;
+  nwg = (ntiles + per - 1) / per;
+  if (gform)
+    TFC_LAUNCH(tfc_first_block_fwd_kernel<true>, dim3(nwg), dim3(256), 0, st, (const bf16_t*)in, IH, IW, (const uint4*)wp, tfc_nb32_padded(64), bias, oscale, slope,
+               (bf16_t*)out, o_pitch, Ho, Wo, sign_mask, N, tiles_y, tiles_x, per);
+  else
+    TFC_LAUNCH(tfc_first_block_fwd_kernel<false>, dim3(nwg), dim3(256), 0, st, (const bf16_t*)in, IH, IW, (const uint4*)wp, tfc_nb32_padded(64), bias, oscale, slope,
+               (bf16_t*)out, o_pitch, Ho, Wo, sign_mask, N, tiles_y, tiles_x, per);
   return hipGetLastError();
 }
 

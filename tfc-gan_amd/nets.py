@@ -172,8 +172,10 @@ class GeneratorCore:
         self._plan.run()
 
     # ---- forward ----
-    def forward(self, x, seed=0, train=True, save=True):
-        """x: fp32 NCHW [N,3,S,S] (S multiple of 64, >= 128). Returns (fake fp32 NCHW in (-1,1), ctx)."""
+    def forward(self, x, seed=0, train=True, save=True, weights_only_first=False):
+        """x: fp32 NCHW [N,3,S,S] (S multiple of 64, >= 128). Returns (fake fp32 NCHW in (-1,1), ctx). weights_only_first: the caller promises a
+        backward with need_input_grad=False (TrainStep): down1 then runs as ONE kernel (conv + LeakyReLU + BlurPool, ops.first_block_fwd) that
+        leaves only sign words for its fused backward -- its 266 MB conv output is never written."""
         ops.require_gpu(x)
         if not self.packed:
             self.repack()
@@ -196,20 +198,29 @@ class GeneratorCore:
         cur = x8
         for i, (name, cin, cout, normalize, drop) in enumerate(G_DOWN):
             h = cur.H
-            raw = new_act(N, h - 1, h - 1, cout, dt, dev)
-            stats = ops.zeros_f32((N, cout, 2), dev) if normalize else None
-            if i == 0 and save and not normalize and ops.first_block_bwd_supported(dt, cin, cout):
-                # the first convolution also leaves one sign bit per output value: all its fused backward (weight gradient only) reads of `raw`
-                ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev)
-                ops.conv_first_fwd(dt, cur, cin, cout, self.packed[name]["fwd"], raw, sign_mask=ctx.mask1)
-            else:
-                ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.packed[name]["fwd"], raw, stats=stats)
             if i < 5:
                 up = skip_of[i]
                 upc = cat[up].C - cout
                 dst = cat[up].sub(upc, cout)
             else:
                 dst = d6
+            first = i == 0 and not normalize and ops.first_block_bwd_supported(dt, cin, cout)
+            if first and (weights_only_first or not save) and drop == 0.0 and getattr(self, "debug", None) is None and ops.first_block_fwd_supported():
+                ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev) if save else None
+                ops.first_block_fwd(dt, cur, cin, cout, self.packed[name]["fwd"], dst, slope=0.2, act_after_rounding=True, sign_mask=ctx.mask1)
+                ctx.raw.append(None)
+                ctx.stats.append(None)
+                ctx.dins.append(cur)
+                cur = dst
+                continue
+            raw = new_act(N, h - 1, h - 1, cout, dt, dev)
+            stats = ops.zeros_f32((N, cout, 2), dev) if normalize else None
+            if first and save:
+                # the first convolution also leaves one sign bit per output value: all its fused backward (weight gradient only) reads of `raw`
+                ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev)
+                ops.conv_first_fwd(dt, cur, cin, cout, self.packed[name]["fwd"], raw, sign_mask=ctx.mask1)
+            else:
+                ops.conv_fwd(dt, OP_CONV, cur, cin, cout, self.packed[name]["fwd"], raw, stats=stats)
             ops.act_fwd(dt, raw, dst, stats=stats, slope=0.2, pool=2, drop_p=drop if train else 0.0, seed=seed * 64 + i)
             ctx.raw.append(raw)
             ctx.stats.append(stats)
@@ -307,7 +318,7 @@ class GeneratorCore:
         for i in range(5, -1, -1):
             name, cin, cout, normalize, drop = G_DOWN[i]
             raw, stats, din = ctx.raw[i], ctx.stats[i], ctx.dins[i]
-            Hc = raw.H
+            Hc = din.H - 1
             dp = drop if ctx.train else 0.0
             sd = ctx.seed * 64 + i
             key = down_weight_key(name)
@@ -322,6 +333,9 @@ class GeneratorCore:
                         hook(key)
                 _on_side(dev, _first_wgrad, g_cur)
                 continue
+            if raw is None:
+                raise ops._lib.TfcError("GeneratorUNet.backward: this forward ran with weights_only_first=True (down1's conv output was not kept); "
+                                   "need_input_grad / debug taps need a forward without it")
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             if normalize:
                 rstats = ops.zeros_f32((N, cout, 2), dev)
@@ -383,7 +397,7 @@ class DiscriminatorCore:
                 self.head_packed[key] = buf
         self._plan.run()
 
-    def forward(self, img_a, img_b, power_iter=True, save=True, after_sn=None):
+    def forward(self, img_a, img_b, power_iter=True, save=True, after_sn=None, weights_only=False):
         """img_a, img_b: fp32 NCHW [N,3,S,S]. Returns (logits View [N,S/16,S/16,pitch 8] channel 0, ctx).
         = sn_snapshot() + chain(). after_sn: called once the power iteration of this call is queued -- everything after it reads only this call's
         snapshots of u, v, sigma, so a second forward may start from there on another stream (forward_pair)."""
@@ -391,7 +405,7 @@ class DiscriminatorCore:
         snapshot = self.sn_snapshot(img_a.device, power_iter, save)
         if after_sn is not None:
             after_sn()
-        return self.chain(img_a, img_b, snapshot, save)
+        return self.chain(img_a, img_b, snapshot, save, weights_only)
 
     def sn_snapshot(self, dev, power_iter=True, save=True):
         """one power iteration of the four spectrally normalised blocks (u, v updated in place as the reference's training-mode forward does) and this
@@ -417,8 +431,10 @@ class DiscriminatorCore:
                                                      v_snaps=vsn if save else None, ws=getattr(self, "_sn_ws", None))
         return usn, vsn, sig
 
-    def chain(self, img_a, img_b, snapshot, save=True):
-        """the convolution chain of one call, given its sn_snapshot()"""
+    def chain(self, img_a, img_b, snapshot, save=True, weights_only=False):
+        """the convolution chain of one call, given its sn_snapshot(). weights_only: the caller promises a backward with need_input_grad=False (the
+        discriminator step); block 1 then runs as one kernel (ops.first_block_fwd) and keeps sign words instead of its 266 MB conv output. A call
+        with save=False takes that kernel too."""
         usn, vsn, sig = snapshot
         dt, dev = self.dt, img_a.device
         N, C, S, _ = img_a.shape
@@ -430,10 +446,21 @@ class DiscriminatorCore:
         for bi, (i, cin, cout) in enumerate(D_BLOCKS):
             sigma2 = sig[bi]
             h = cur.H
+            first = bi == 0 and ops.first_block_bwd_supported(dt, cin, cout)
+            if first and (weights_only or not save) and getattr(self, "debug", None) is None and ops.first_block_fwd_supported():
+                ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev) if save else None
+                out = new_act(N, pooled(h - 1), pooled(h - 1), cout, dt, dev)
+                ops.first_block_fwd(dt, cur, cin, cout, self.head_packed[f"f{i}"], out, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:],
+                                    slope=0.2, act_after_rounding=False, sign_mask=ctx.mask1)
+                ctx.ins.append(cur)
+                ctx.raw.append(None)
+                ctx.sn.append((usn[bi], vsn[bi], sigma2) if save else None)
+                cur = out
+                continue
             raw = new_act(N, h - 1, h - 1, cout, dt, dev)
             # SN-conv + bias + LeakyReLU(0.2) in one kernel (P16:188-190): `raw` holds the ACTIVATED tensor; the backward's slope test
             # (y > 0) is the same on y = LeakyReLU(z) as on z, so act_bwd below keeps slope = 0.2 on this tensor
-            if bi == 0 and save and ops.first_block_bwd_supported(dt, cin, cout):
+            if first and save:
                 ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev)       # sign bits for the fused backward of block 1
                 ops.conv_first_fwd(dt, cur, cin, cout, self.head_packed[f"f{i}"], raw, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:],
                                    flags=ops.EP_LEAKY, sign_mask=ctx.mask1)
@@ -451,20 +478,20 @@ class DiscriminatorCore:
         ctx.p4 = cur
         return View(logits.t, 1, 0), (ctx if save else None)
 
-    def forward_pair(self, a1, b1, a2, b2, power_iter=True, save=True):
+    def forward_pair(self, a1, b1, a2, b2, power_iter=True, save=True, weights_only=False):
         """forward(a1, b1) then forward(a2, b2), same results as the two calls in that order (the second power iteration follows the first). With the
         side stream on, the second call's convolution chain runs beside the first's: two independent chains of MFMA-bound GEMMs and HBM-bound
         blur-pools that fill each other's gaps."""
         if not _side_active() or os.environ.get("TFC_NO_FWD_PAIR", "0") not in ("", "0"):    # (A/B knob)
-            return self.forward(a1, b1, power_iter, save), self.forward(a2, b2, power_iter, save)
+            return self.forward(a1, b1, power_iter, save, None, weights_only), self.forward(a2, b2, power_iter, save, None, weights_only)
         dev = a1.device
         if not self.head_packed:
             self.repack()
         box = {}
 
         def second():
-            box["r"] = _on_side(dev, lambda: self.forward(a2, b2, power_iter, save))
-        first = self.forward(a1, b1, power_iter, save, after_sn=second)
+            box["r"] = _on_side(dev, lambda: self.forward(a2, b2, power_iter, save, None, weights_only))
+        first = self.forward(a1, b1, power_iter, save, after_sn=second, weights_only=weights_only)
         _join_side(dev)
         return first, box["r"]
 
@@ -494,7 +521,7 @@ class DiscriminatorCore:
             i, cin, cout = D_BLOCKS[bi]
             raw, xin = ctx.raw[bi], ctx.ins[bi]
             u, v, sigma2 = ctx.sn[bi]
-            Hc = raw.H
+            Hc = xin.H - 1
             gb_img = ops.zeros_f32((N, cout), dev) if grads is not None else None
             fuse = (bi == 0 and grads is not None and not need_input_grad and getattr(self, "debug", None) is None
                     and ops.first_block_bwd_supported(dt, cin, cout))
@@ -515,6 +542,9 @@ class DiscriminatorCore:
                         hook(f"model.{i}.bias")
                 _on_side(dev, _first_wgrad, g_cur, gb_img)
                 continue
+            if raw is None:
+                raise ops._lib.TfcError("Discriminator1.backward: this forward ran with weights_only=True (block 1's conv output was not kept); "
+                                   "need_input_grad / grads=None / debug taps need a forward without it")
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
             ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
             ddbg = getattr(self, "debug", None)

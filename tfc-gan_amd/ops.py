@@ -215,6 +215,10 @@ def first_block_bwd_supported(dt, Cin, Cout):
     return bool(lib().tfc_first_block_bwd_supported(dt, Cin, Cout))
 
 
+def first_block_fwd_supported():
+    return not os.environ.get("TFC_NO_FUSED_FIRST_FWD")           # A/B knob for profiling (read per call)
+
+
 def conv_first_fwd(dt, x: View, Cin, Cout, packed, y: View, bias=None, oscale=None, flags=0, sign_mask=None):
     """first convolution of a network (8 padded input channels -> 64) on the weights-stationary kernel; sign_mask: uint8 [N, H-1, W-1, 8] that receives
     one bit per stored value (> 0) for the fused backward of the block"""
@@ -222,6 +226,13 @@ def conv_first_fwd(dt, x: View, Cin, Cout, packed, y: View, bias=None, oscale=No
         flags |= EP_BIAS
     check(lib().tfc_conv_first_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, Cin, Cout, _p(packed), y.ptr, y.pitch, _p(bias), _p(oscale), flags,
                                    _p(sign_mask)), "tfc_conv_first_fwd")
+
+
+def first_block_fwd(dt, x: View, Cin, Cout, packed, out: View, bias=None, oscale=None, slope=0.2, act_after_rounding=False, sign_mask=None):
+    """conv -> [+bias, x 1/sigma] -> LeakyReLU -> BlurPool(stride 2) of a first block in one kernel (the conv output is never written); `out` may be a
+    channel window of a wider buffer"""
+    check(lib().tfc_first_block_fwd(stream_ptr(), dt, x.ptr, x.pitch, x.N, x.H, x.W, Cin, Cout, _p(packed), _p(bias), _p(oscale), slope,
+                                    1 if act_after_rounding else 0, out.ptr, out.pitch, _p(sign_mask)), "tfc_first_block_fwd")
 
 
 def first_block_bwd_wgrad(dt, x: View, y: View, dy_pooled: View, Cin, Cout, dw, slope=0.2, accumulate=False, ws=None, bias_sums=None, sign_mask=None):
