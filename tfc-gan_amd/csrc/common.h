@@ -8,6 +8,7 @@ typedef unsigned short bf16_t;                                   // raw bf16 sto
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;      // one MFMA 32x32x16 operand fragment
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 

@@ -3444,10 +3444,20 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
   constexpr int HB = HHH * P * PS;                               // 8320
   constexpr int NK = 320, PLANE = NK * 64;                       // conv pixels of a tile; one 32-channel plane [k][32 ch]
   constexpr int PP = 400, PB = 32 * PP;                          // tap matrix of a block: [32 pooled px][192 k] bf16, 400-byte rows (conflict-free 16-byte reads)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[HB + 2 * PLANE + 2 * PB + NK * 8];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HB + 2 * PLANE + 2 * PB + NK * 16];
   unsigned char* planes = smem + HB;
   unsigned char* pmat = planes + 2 * PLANE;
-  unsigned* smask = reinterpret_cast<unsigned*>(pmat + 2 * PB);  // [320 conv px][2 channel halves]
+  unsigned* smask = reinterpret_cast<unsigned*>(pmat + 2 * PB);  // [320 conv px][2 channel halves][2 lane halves]: partial sign words, OR-ed by the reader
+#ifdef TFC_STAMP
+  long long* stamp_out = reinterpret_cast<long long*>(sign_mask);   // diagnostic build: phase totals per wave instead of the sign words
+  sign_mask = nullptr;
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};                    // [7]: tap-matrix builds
+  unsigned long long tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev) :: "memory");
+#define FB_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ph[i] += (long long)(t_ - tprev); tprev = t_; } while (0)
+#else
+#define FB_STAMP(i) do { } while (0)
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3458,9 +3468,17 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
   uint4 bw[8];                                                   // this wave's 32 output channels x K = 128, for the whole launch
 #pragma unroll
   for (int s = 0; s < 8; ++s) bw[s] = wp[((size_t)s * NB32 + wn) * 64 + lane];
-  const int n = wn * 32 + r;
-  const float bv = bias ? bias[n] : 0.f;
+  // swapped MFMA operands (weights as A): a lane holds 16 channels {8 q4 + 4 h + e} of ONE conv pixel -> 8-byte LDS stores, sign bits by packed integer ops
+  float bvv[16];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const float4 t = bias ? *reinterpret_cast<const float4*>(bias + wn * 32 + 8 * q4 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bvv[4 * q4] = t.x; bvv[4 * q4 + 1] = t.y; bvv[4 * q4 + 2] = t.z; bvv[4 * q4 + 3] = t.w;
+  }
   const float osc = oscale ? *oscale : 1.f;
+  // plane rows are 64 bytes (eight 8-byte chunks); chunk c of row k lives at c ^ sw(k), sw(k) = ((k >> 2) & 3) | (((k >> 5) & 1) << 2): the epilogue's
+  // 8-byte stores (lane = pixel: k steps by 1 per two lanes, by 32 between them) and the transposing reads of the pooling GEMM are both conflict-free
+  const int swl = ((r >> 3) & 3) | ((r & 1) << 2);
 
   const int tpi = tiles_y * tiles_x;
   const int ntiles = nimg * tpi;
@@ -3474,21 +3492,30 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
   // conv row / column of region pixel (0, 0): 2 oy0 - 1 -- one less when the tile's FIRST pooled row (column) is the image's last one and the conv size is
   // odd: its tap 2 oy + 2 = CH + 1 then reflects to CH - 3 = 2 oy0 - 2, in front of the usual origin (the rows behind are unused in that tile)
   auto origin = [&](int o0, int Lo, int L) { return 2 * o0 - 1 - ((o0 == Lo - 1 && L == 2 * o0 + 1) ? 1 : 0); };
-  auto halo_load = [&](int tl) {
-    const int img = tl / tpi, rem = tl - img * tpi;
-    const int tyb = rem / tiles_x, txb = rem - tyb * tiles_x;
+  bool hok[2];
+  // always two loads per thread (clamped address + validity flag applied at the LDS store): straight-line code, so that the compiler's wait counts are exact
+  // tiles are walked column-major inside an image (the border class -- tap matrices -- changes 3 times per column of tiles); positions advance
+  // incrementally (the divisions of a decode cost a wave ~450 cycles per tile)
+  struct Pos { int img, txb, tyb; };
+  auto decode = [&](int tl) { Pos q; q.img = tl / tpi; const int rem = tl - q.img * tpi; q.txb = rem / tiles_y; q.tyb = rem - q.txb * tiles_y; return q; };
+  auto advance = [&](Pos& q) {
+    if (++q.tyb == tiles_y) { q.tyb = 0; if (++q.txb == tiles_x) { q.txb = 0; ++q.img; } }
+  };
+  auto halo_load = [&](const Pos& q) {
+    const int img = q.img, txb = q.txb, tyb = q.tyb;
     const int y0 = origin(4 * tyb, Ho, CH) - 1, x0 = origin(15 * txb, Wo, CW) - 1;   // input row / column of halo pixel (0, 0): conv row c reads input rows from c - 1
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      hv[i] = make_uint4(0, 0, 0, 0);
       const int y = y0 + hy_[i], x = x0 + hx_[i];
-      if (hy_[i] < HHH && y >= 0 && y < IH && x >= 0 && x < IW) hv[i] = *reinterpret_cast<const uint4*>(in + ((size_t)(img * IH + y) * IW + x) * 8);
+      hok[i] = hy_[i] < HHH && y >= 0 && y < IH && x >= 0 && x < IW;
+      const int yc = hok[i] ? y : 0, xc = hok[i] ? x : 0;
+      hv[i] = *reinterpret_cast<const uint4*>(in + ((size_t)(img * IH + yc) * IW + xc) * 8);
     }
   };
   auto halo_store = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      if (hy_[i] < HHH) *reinterpret_cast<uint4*>(smem + (hy_[i] * P + hx_[i]) * PS) = hv[i];
+      if (hy_[i] < HHH) *reinterpret_cast<uint4*>(smem + (hy_[i] * P + hx_[i]) * PS) = hok[i] ? hv[i] : make_uint4(0, 0, 0, 0);
   };
   auto refl = [](int v, int L) { return v < 0 ? -v : (v >= L ? 2 * L - 2 - v : v); };
   // first region row of the 6-row K window of block b (pooled rows oy0 + 2b, + 1): the smallest conv row its valid pooled rows touch (reflect aliases
@@ -3503,32 +3530,48 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
     const int w = lo == (1 << 30) ? 4 * b : lo - cr0;
     return w < 0 ? 0 : (w > 4 ? 4 : w);
   };
-  // the tap matrix of block b (pooled rows 2b, 2b + 1 of the tile): thread p < 32 owns pooled pixel p = pr * 16 + pc
+  // the tap matrix of block b (pooled rows 2b, 2b + 1 of the tile), P[p = pr * 16 + pc][k = rr * 32 + cc] = R[pr][rr] * C[pc][cc]: the per-row and per-column
+  // tap sums (reflect aliases merged; multiples of 1/8) are tabulated first, the products (multiples of 1/64 <= 1: exact in bf16) written 8 at a time.
+  // The tables overlay the sign-word buffer, which is idle here (written by the epilogue after the build's last barrier, read before the next build).
   auto pmat_build = [&](int b, int oy0, int ox0) {
     unsigned char* pm = pmat + b * PB;
-    for (int i = tid; i < PB / 16; i += 256) *reinterpret_cast<uint4*>(pm + i * 16) = make_uint4(0, 0, 0, 0);
+    float* Ct = reinterpret_cast<float*>(smask);                  // [16][32]
+    float* Rt = Ct + 16 * 32;                                     // [2][8]
+    const int rg0 = origin(oy0, Ho, CH);
+    const int cr0 = rg0 + win_start(b, oy0, rg0), cc0 = origin(ox0, Wo, CW);   // conv row / column of k = 0 of this block
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256, pc = e >> 5, cc = e & 31;
+      const int ox = ox0 + pc;
+      float w = 0.f;
+      if (pc < 15 && ox < Wo)
+        for (int j = 0; j < 4; ++j)
+          if (refl(2 * ox - 1 + j, CW) - cc0 == cc) w += (j == 0 || j == 3) ? 0.125f : 0.375f;
+      Ct[e] = w;
+    }
+    if (tid < 16) {
+      const int pr = tid >> 3, rr = tid & 7;
+      const int oy = oy0 + 2 * b + pr;
+      float w = 0.f;
+      if (rr < 6 && oy < Ho)
+        for (int i = 0; i < 4; ++i)
+          if (refl(2 * oy - 1 + i, CH) - cr0 == rr) w += (i == 0 || i == 3) ? 0.125f : 0.375f;
+      Rt[tid] = w;
+    }
     __syncthreads();
-    if (tid < 32) {
-      const int pr = tid >> 4, pc = tid & 15;
-      const int oy = oy0 + 2 * b + pr, ox = ox0 + pc;
-      if (pc < 15 && oy < Ho && ox < Wo) {
-        bf16_t* row = reinterpret_cast<bf16_t*>(pm + tid * PP);
-        const int rg0 = origin(oy0, Ho, CH);
-        const int cr0 = rg0 + win_start(b, oy0, rg0), cc0 = origin(ox0, Wo, CW);   // conv row / column of k = 0 of this block
-        for (int i = 0; i < 4; ++i) {
-          const int y = refl(2 * oy - 1 + i, CH);
-          const int rr = y - cr0;
-          for (int j = 0; j < 4; ++j) {
-            const int x = refl(2 * ox - 1 + j, CW);
-            const int cc = x - cc0;
-            if (rr >= 0 && rr < 6 && cc >= 0 && cc < 32) {
-              const float w = ((i == 0 || i == 3) ? 0.125f : 0.375f) * ((j == 0 || j == 3) ? 0.125f : 0.375f);
-              bf16_t* e = row + rr * 32 + cc;
-              *e = f32_to_bf16(bf16_to_f32(*e) + w);             // reflect aliases merge; every partial sum is a multiple of 1/64 <= 1: exact
-            }
-          }
-        }
-      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int u = tid + i * 256;                                // 768 units of 8 entries
+      const int pp = u / 24, k0 = (u - pp * 24) * 8;
+      const float rw = Rt[(pp >> 4) * 8 + (k0 >> 5)];
+      const float4 c0 = *reinterpret_cast<const float4*>(Ct + (pp & 15) * 32 + (k0 & 31));
+      const float4 c1 = *reinterpret_cast<const float4*>(Ct + (pp & 15) * 32 + (k0 & 31) + 4);
+      uint4 o;
+      o.x = pack_bf16x2(rw * c0.x, rw * c0.y);
+      o.y = pack_bf16x2(rw * c0.z, rw * c0.w);
+      o.z = pack_bf16x2(rw * c1.x, rw * c1.y);
+      o.w = pack_bf16x2(rw * c1.z, rw * c1.w);
+      *reinterpret_cast<uint4*>(pm + pp * PP + k0 * 2) = o;
     }
     __syncthreads();
   };
@@ -3536,10 +3579,13 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
 
   const int grp = lane >> 4, li = lane & 15;
   const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, pq = li & 3;
-  const int trA = (8 * hk + q) * 64 + cb16 * 32 + pq * 8;
-  auto tr16 = [&](const unsigned char* p0) {
-    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
-    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + 4 * 64));
+  const int c8 = cb16 * 4 + pq;
+  // [row parity of the 32-row group][low / high four rows]: byte offset of this lane's 8-byte chunk in a 16-row k-step
+  const int trLo0 = (8 * hk + q) * 64 + ((c8 ^ (2 * hk)) * 8), trHi0 = (8 * hk + q + 4) * 64 + ((c8 ^ (2 * hk + 1)) * 8);
+  const int trLo1 = (8 * hk + q) * 64 + ((c8 ^ (2 * hk) ^ 4) * 8), trHi1 = (8 * hk + q + 4) * 64 + ((c8 ^ (2 * hk + 1) ^ 4) * 8);
+  auto tr16 = [&](const unsigned char* p0, int olo, int ohi) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + olo));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + ohi));
     uint4 o;
     o.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
     o.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
@@ -3548,57 +3594,19 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
     return o;
   };
 
-  halo_load(t0);
+  Pos cur = decode(t0), pre = cur;                                // pre: the tile whose halo is requested next (at most t1 - 1)
+  int pre_tl = t0;
+  halo_load(pre);
   halo_store();
   __syncthreads();
-  for (int tl = t0; tl < t1; ++tl) {
-    const int img = tl / tpi, rem = tl - img * tpi;
-    const int tyb = rem / tiles_x, txb = rem - tyb * tiles_x;
+  if (pre_tl + 1 < t1) { ++pre_tl; advance(pre); }
+  halo_load(pre);                                                 // two tiles ahead from here on: the loads of tile t + 2 are issued in front of tile t's output stores
+  for (int tl = t0; tl < t1; ++tl, advance(cur)) {
+    const int img = cur.img, txb = cur.txb, tyb = cur.tyb;
     const int oy0 = 4 * tyb, ox0 = 15 * txb;
     const bool more = tl + 1 < t1;
-    if (more) halo_load(tl + 1);                                  // into registers; the LDS halo is rewritten behind the conv phase
-    // ---- 1. convolution of the 10 x 32 region: subtile m = (row pair rp = m >> 1, column half m & 1); wave (wm, wn): m = 5 wm .. 5 wm + 4 ----
-    f32x16_t acc[5];
-#pragma unroll
-    for (int mi = 0; mi < 5; ++mi)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 5; ++mi) {
-      const int m = 5 * wm + mi;
-      const unsigned char* buf = smem + ((2 * (m >> 1) + (r & 1)) * P + 16 * (m & 1) + (r >> 1)) * PS + h * PS;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const uint4 a = *reinterpret_cast<const uint4*>(buf + ((s >> 1) * P + 2 * (s & 1)) * PS);
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bw[s]), acc[mi], 0, 0, 0);
-      }
-    }
-    __syncthreads();                                              // halo consumed
-    if (more) halo_store();
-    // ---- 2. epilogue: the value the unfused chain would store (bf16), into the planes; its sign into the sign words ----
-    tfc_static_for<0, 5>([&](auto mic) {
-      constexpr int mi = decltype(mic)::value;
-      const int m = 5 * wm + mi;
-      unsigned mw = 0;
-      tfc_static_for<0, 16>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-        const int k = (2 * (m >> 1) + (row & 1)) * 32 + 16 * (m & 1) + (row >> 1);
-        float v = acc[mi][j] * osc + bv;
-        if (!GFORM) v = fmaxf(v, slope * v);                       // form D: LeakyReLU before the rounding (conv epilogue of the unfused chain)
-        const bf16_t hb = f32_to_bf16(v);
-        *reinterpret_cast<bf16_t*>(planes + wn * PLANE + k * 64 + r * 2) = hb;
-        const unsigned long long bal = __ballot((short)hb > 0);
-        constexpr int r0 = (j & 3) + 8 * (j >> 2);
-        mw = tfc_writelane<r0>((unsigned)bal, mw);
-        mw = tfc_writelane<r0 + 4>((unsigned)(bal >> 32), mw);
-      });
-      if (lane < 32) {                                             // lane = pixel row of subtile m
-        const int k = (2 * (m >> 1) + (lane & 1)) * 32 + 16 * (m & 1) + (lane >> 1);
-        smask[k * 2 + wn] = mw;
-      }
-    });
-    // the tap matrices of this tile (rebuilt only when the border class of a block changes)
+    FB_STAMP(6);
+    // the tap matrices of this tile (rebuilt only when the border class of a block changes; here, while the sign-word buffer they borrow is idle)
     {
       const int kx = (ox0 == 0 || 2 * (ox0 + 15) + 1 >= CW) ? ox0 : -1;
       bool rb[2];
@@ -3613,13 +3621,79 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
       if (rb[0]) pmat_build(0, oy0, ox0);
       if (rb[1]) pmat_build(1, oy0, ox0);
     }
-    __syncthreads();                                              // planes, sign words (and tap matrices) visible
+    FB_STAMP(7);
+    // ---- 1. convolution of the 10 x 32 region: subtile m = (row pair rp = m >> 1, column half m & 1); wave (wm, wn): m = 5 wm .. 5 wm + 4 ----
+    f32x16_t acc[5];
+#pragma unroll
+    for (int mi = 0; mi < 5; ++mi)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][j] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 5; ++mi) {
+      const int m = 5 * wm + mi;
+      const unsigned char* buf = smem + ((2 * (m >> 1) + (r & 1)) * P + 16 * (m & 1) + (r >> 1)) * PS + h * PS;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const uint4 a = *reinterpret_cast<const uint4*>(buf + ((s >> 1) * P + 2 * (s & 1)) * PS);
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bw[s]), __builtin_bit_cast(bf16x8_t, a), acc[mi], 0, 0, 0);
+      }
+    }
+    FB_STAMP(0);
+    __syncthreads();                                              // halo consumed
+    FB_STAMP(1);
+    if (more) halo_store();                                       // tile tl + 1 (requested a tile ago)
+    if (pre_tl + 1 < t1) { ++pre_tl; advance(pre); }
+    halo_load(pre);                                               // (the last tiles re-request the last halo: no branch around a load)
+    // ---- 2. epilogue: the value the unfused chain would store (bf16), into the planes; its sign into the sign words ----
+    tfc_static_for<0, 5>([&](auto mic) {
+      constexpr int mi = decltype(mic)::value;
+      const int m = 5 * wm + mi;
+      const int kpx = (2 * (m >> 1) + (r & 1)) * 32 + 16 * (m & 1) + (r >> 1);   // this lane's conv pixel
+      unsigned char* prow = planes + wn * PLANE + kpx * 64;
+      unsigned slo = 0, shi = 0;
+      tfc_static_for<0, 4>([&](auto qc) {
+        constexpr int q4 = decltype(qc)::value;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[mi][4 * q4 + e] * osc + bvv[4 * q4 + e];
+          if (!GFORM) v[e] = fmaxf(v[e], slope * v[e]);             // form D: LeakyReLU before the rounding (conv epilogue of the unfused chain)
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(prow + (((2 * q4 + h) ^ swl) * 8)) = o;
+        if (sign_mask) {
+          // (short)x > 0 per half: clamp to [0, 1] ([0, 2] in the high half) as signed 16-bit integers, then one dot2 puts both bits at 8 q4 + 2 i (+ 1)
+          constexpr unsigned one_two = 0x00020001u;
+          const s16x2_t lim = __builtin_bit_cast(s16x2_t, one_two), z = {0, 0};
+          const u16x2_t c0 = __builtin_bit_cast(u16x2_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s16x2_t, o.x), z), lim));
+          const u16x2_t c1 = __builtin_bit_cast(u16x2_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s16x2_t, o.y), z), lim));
+          constexpr unsigned short w0 = 1u << (8 * (q4 & 1)), w1 = 1u << (8 * (q4 & 1) + 2);
+          const u16x2_t g0 = {w0, w0}, g1 = {w1, w1};
+          if (q4 < 2) {
+            slo = __builtin_amdgcn_udot2(c0, g0, slo, false);
+            slo = __builtin_amdgcn_udot2(c1, g1, slo, false);
+          } else {
+            shi = __builtin_amdgcn_udot2(c0, g0, shi, false);
+            shi = __builtin_amdgcn_udot2(c1, g1, shi, false);
+          }
+        }
+      });
+      if (sign_mask) smask[kpx * 4 + wn * 2 + h] = (slo | (shi << 16)) << (4 * h);
+    });
+    FB_STAMP(2);
+    __syncthreads();                                              // planes and sign words visible
+    FB_STAMP(3);
     // ---- 3. sign words of the conv pixels this tile owns: region rows 1..8, columns 1..30 ----
     if (sign_mask && tid < 240) {
       const int y = 2 * oy0 + tid / 30, x = 2 * ox0 + tid % 30;    // the tile owns conv rows 2 oy0 .. + 7, columns 2 ox0 .. + 29
       const int rr = y - origin(oy0, Ho, CH), cc = x - origin(ox0, Wo, CW);
       if (y < CH && x < CW && rr < 10 && cc < 32)
-        *reinterpret_cast<uint2*>(sign_mask + ((size_t)(img * CH + y) * CW + x) * 8) = *reinterpret_cast<const uint2*>(smask + (rr * 32 + cc) * 2);
+      {
+        const uint4 pw = *reinterpret_cast<const uint4*>(smask + (rr * 32 + cc) * 4);
+        *reinterpret_cast<uint2*>(sign_mask + ((size_t)(img * CH + y) * CW + x) * 8) = make_uint2(pw.x | pw.y, pw.z | pw.w);
+      }
     }
     // ---- 4. BlurPool as a GEMM: wave = (block b, 32-channel plane cb) ----
     {
@@ -3627,11 +3701,14 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
       f32x16_t gp, gn;
 #pragma unroll
       for (int j = 0; j < 16; ++j) { gp[j] = 0.f; gn[j] = 0.f; }
-      const unsigned char* pa = planes + cb * PLANE + (32 * win_start(b, oy0, origin(oy0, Ho, CH))) * 64 + trA;
+      const int wst = win_start(b, oy0, origin(oy0, Ho, CH));
+      const unsigned char* pa = planes + cb * PLANE + (32 * wst) * 64;
+      const bool wodd = wst & 1;                                      // parity of the first 32-row group of the window (wave-uniform)
+      const int oL0 = wodd ? trLo1 : trLo0, oH0 = wodd ? trHi1 : trHi0, oL1 = wodd ? trLo0 : trLo1, oH1 = wodd ? trHi0 : trHi1;
       const unsigned char* pb = pmat + b * PB + r * PP + 8 * h * 2;
 #pragma unroll
       for (int ks = 0; ks < 12; ++ks) {
-        const uint4 a = tr16(pa + ks * 16 * 64);
+        const uint4 a = ((ks >> 1) & 1) ? tr16(pa + ks * 16 * 64, oL1, oH1) : tr16(pa + ks * 16 * 64, oL0, oH0);
         const uint4 bm = *reinterpret_cast<const uint4*>(pb + ks * 32);
         if constexpr (GFORM) {
           uint4 ap, an;                                            // max(y, 0) and min(y, 0) on the sign-magnitude bits of the bf16 pairs
@@ -3646,25 +3723,37 @@ tfc_first_block_fwd_kernel(const bf16_t* __restrict__ in, int IH, int IW, const 
           gp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bm), gp, 0, 0, 0);
         }
       }
+      FB_STAMP(4);
       // lane (pooled pixel r of the block, half h): 16 channels {8 q4 + 4 h + e} of plane cb
       const int pr = r >> 4, pc = r & 15;
       const int oy = oy0 + 2 * b + pr, ox = ox0 + pc;
-      if (pc < 15 && oy < Ho && ox < Wo) {
-        bf16_t* po = out + ((size_t)(img * Ho + oy) * Wo + ox) * o_pitch + cb * 32 + 4 * h;
+      // (the lane swaps below are whole-wave operations: outside the bounds test)
+      unsigned pk[4][2];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          float v[4];
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = GFORM ? gp[4 * q4 + e] + slope * gn[4 * q4 + e] : gp[4 * q4 + e];
-          uint2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2*>(po + 8 * q4) = o;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = GFORM ? gp[4 * q4 + e] + slope * gn[4 * q4 + e] : gp[4 * q4 + e];
+        pk[q4][0] = pack_bf16x2(v[0], v[1]);
+        pk[q4][1] = pack_bf16x2(v[2], v[3]);
+      }
+#pragma unroll
+      for (int pr2 = 0; pr2 < 2; ++pr2) {
+        // lanes < 32 hold channels 8q+0..3 (q = 2 pr2) and want 8q+4..7 from lane + 32, which wants this lane's group 2 pr2 + 1: 16 bytes per lane
+        auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr2][0], pk[2 * pr2 + 1][0], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr2][1], pk[2 * pr2 + 1][1], false, false);
+        if (pc < 15 && oy < Ho && ox < Wo)
+          *reinterpret_cast<uint4*>(out + ((size_t)(img * Ho + oy) * Wo + ox) * o_pitch + cb * 32 + pr2 * 16 + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
       }
     }
+    FB_STAMP(5);
     __syncthreads();                                              // planes / sign words free for the next tile
   }
+#ifdef TFC_STAMP
+  if (stamp_out && lane == 0)
+    for (int i = 0; i < 8; ++i) stamp_out[(blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+#endif
+#undef FB_STAMP
 }
 
 // first-layer shape (8 padded input channels, 4 x 4 raster taps, <= 64 output channels, bias / scale / LeakyReLU epilogue only)?
