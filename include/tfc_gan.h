@@ -132,6 +132,10 @@ int tfc_act_fwd(void* stream, int dt, const void* x, int x_pitch, int N, int H, 
                 float slope, int pool, float drop_p, uint32_t seed, void* y, int y_pitch, float* stats_out, float* part_ws);
 int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int dy_pitch, const void* x, int x_pitch, int N, int H, int W, int C,
                 const float* stats, int norm, float slope, int pool, float drop_p, uint32_t seed, float* rstats, void* dx, int dx_pitch, float* part_ws);
+/* tfc_act_bwd(mode 0, pool 2, norm 0) for a 64-channel bf16 tensor x that was never stored: sign_mask = its sign words (uint8 [N][H][W][8], bit c of the
+ * 64-bit word of a pixel = (x[c] > 0), as tfc_first_block_fwd / tfc_conv_first_fwd leave them). Same dx bits as tfc_act_bwd on the stored tensor. */
+int tfc_act_bwd_signs(void* stream, int dt, const void* dy, int dy_pitch, const unsigned char* sign_mask, int N, int H, int W, int C, float slope,
+                      float* rstats, void* dx, int dx_pitch, float* part_ws);
 int tfc_dropout_mask(void* stream, uint8_t* keep, long long n, float drop_p, uint32_t seed);   /* test hook: the mask itself */
 
 /* ---- layout plumbing at the NCHW fp32 module boundary -------------------------------------------------------------- */

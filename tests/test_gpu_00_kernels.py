@@ -347,6 +347,31 @@ def test_fused_first_block_forward_equals_unfused_chain(N, S, Cin, gform):
     assert frac <= 2e-2, frac
 
 
+@pytest.mark.parametrize("N,S,with_bias", [(2, 256, True), (1, 70, False), (3, 41, True)])
+def test_blurpool_backward_from_sign_words_equals_the_stored_tensor_form(N, S, with_bias):
+    """tfc_act_bwd_signs (LeakyReLU' from the sign words a first block leaves instead of its conv output) gives the bits of tfc_act_bwd(mode 0, pool 2) on the
+    stored tensor, incl. the per-image bias-gradient sums"""
+    dt = DT_BF16
+    H = S - 1
+    Po = (H - 1) // 2 + 1
+    xv = to_view(q(rnd((N, 6, S, S), 41), dt), dt)
+    w = rnd((64, 6, 4, 4), 42, 0.3).to(DEV)
+    pk = ops.pack_weight(dt, ops.OP_CONV, 0, w, 6, 64)
+    raw = ops.new_act(N, H, H, 64, dt, DEV)
+    mask = torch.zeros((N, H, H, 8), dtype=torch.uint8, device=DEV)
+    ops.conv_first_fwd(dt, xv, 6, 64, pk, raw, flags=ops.EP_LEAKY, sign_mask=mask)
+    g = to_view(q(rnd((N, 64, Po, Po), 43), dt), dt)
+    da, db = ops.new_act(N, H, H, 64, dt, DEV), ops.new_act(N, H, H, 64, dt, DEV)
+    ra = torch.zeros((N, 64), device=DEV) if with_bias else None
+    rb = torch.zeros((N, 64), device=DEV) if with_bias else None
+    ops.act_bwd(dt, 0, g, raw, N, H, H, 64, da, stats=None, slope=0.2, pool=2, rstats=ra)
+    ops.act_bwd_signs(dt, g, mask, N, H, H, 64, db, slope=0.2, rstats=rb)
+    torch.cuda.synchronize()
+    assert torch.equal(da.t, db.t)
+    if with_bias:
+        assert torch.equal(ra, rb)
+
+
 def test_planned_pack_equals_single_pack():
     """tfc_conv_pack_planned (one launch for every operand stream of a network; single-slot taps take a scan-free path) writes the same bytes
     as tfc_conv_pack, for every op and pass of the path -- plain, flipped (dgrad), phase-split (transposed conv), collapsed (upsample head), 3x3"""

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "tfc_conv_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "tfc_conv_wgrad": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
     "tfc_act_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _i, _vp, _vp]),
+    "tfc_act_bwd_signs": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "tfc_act_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _f, _u32, _vp, _vp, _i, _vp]),
     "tfc_dropout_mask": (_i, [_vp, _vp, _ll, _f, _u32]),
     "tfc_pack_nhwc8": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i]),

@@ -52,6 +52,7 @@ hipError_t tfc_launch_wgrad_finish(float* acc, float* grad, int Nn, int Cw, long
 hipError_t tfc_launch_pack_planned(int dt, const void* plan_dev, int njobs, int nblocks, hipStream_t st);
 hipError_t tfc_launch_act_fwd(int dt, const ActParams& p, const void* x, const float* stats, void* out, float* stats_out, float* part_ws, hipStream_t st);
 hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats, float* rstats, void* dx, int use_x, int dx_pitch, float* part_ws, hipStream_t st);
+hipError_t tfc_launch_act_pool2_bwd_signs(const ActParams& p, const void* dout, const unsigned char* sign_mask, float* rstats, void* dx, int dx_pitch, float* part_ws, hipStream_t st);
 hipError_t tfc_launch_colsum(int dt, const void* x, long long rows, int pitch, int C, float* out, float* part_ws, hipStream_t st);
 hipError_t tfc_launch_pack_nhwc8(int dt, const float* a, int Ca, const float* b, int Cb, void* out, int N, int HW, hipStream_t st);
 hipError_t tfc_launch_unpack_nchw(int dt, const void* in, int pitch, int c0, int C, float* out, int N, int HW, float alpha, float beta, hipStream_t st);
@@ -723,6 +724,18 @@ extern "C" int tfc_act_bwd(void* stream, int dt, int mode, const void* dy, int d
   REQUIRE(!(mode == 1 || (mode == 0 && rstats)) || part_ws, "a reduction into rstats needs part_ws");
   const void* xx = x ? x : dy;
   CHECK_HIP(tfc_launch_act_bwd(dt, mode, p, dy, xx, stats, rstats, dx ? dx : (void*)dy, x ? 1 : 0, dx_pitch, part_ws, (hipStream_t)stream), "tfc_act_bwd");
+  return 0;
+}
+
+extern "C" int tfc_act_bwd_signs(void* stream, int dt, const void* dy, int dy_pitch, const unsigned char* sign_mask, int N, int H, int W, int C, float slope,
+                                 float* rstats, void* dx, int dx_pitch, float* part_ws) {
+  ActParams p;
+  REQUIRE(dt == TFC_DT_BF16 && C == 64, "tfc_act_bwd_signs: bf16, 64 channels");
+  if (int e = fill_act(p, dt, N, H, W, C, C, dy_pitch, 0, slope, 2, 0.f, 0)) return e;
+  if (int e = check_ptr16(dy, "dy")) return e;
+  REQUIRE(sign_mask && dx, "sign_mask / dx is null");
+  REQUIRE(!rstats || part_ws, "a reduction into rstats needs part_ws");
+  CHECK_HIP(tfc_launch_act_pool2_bwd_signs(p, dy, sign_mask, rstats, dx, dx_pitch, part_ws, (hipStream_t)stream), "tfc_act_bwd_signs");
   return 0;
 }
 

@@ -407,8 +407,9 @@ tfc_act_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __res
 // window of the pooled gradient that the tile's interior pixels read is staged ONCE in LDS (with the dropout mask applied once
 // per element, not once per tap); each pixel then takes its 2 x 2 taps (3 x 3 next to the bottom / right reflect border) from
 // LDS with weights tabulated per tile row / column, so interior and border pixels run the same short code.
-// MODE as in tfc_act_bwd_kernel.
-template <typename T, int MODE, bool NORM>
+// MODE as in tfc_act_bwd_kernel. SIGNW (mode 0, 64 channels): `x` is not the activation but its sign words (8 bytes per pixel, bit c = (x[c] > 0), as
+// tfc_first_block_fwd / tfc_conv_first_fwd leave them) -- a thread reads the ONE byte of its eight channels instead of 16 bytes.
+template <typename T, int MODE, bool NORM, bool SIGNW = false>
 __global__ void __launch_bounds__(256)
 tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T* __restrict__ x, const float* __restrict__ stats,
                          float* rstats, T* __restrict__ dx, int dx_pitch, int tiles_x, int cslice) {
@@ -426,6 +427,7 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
   const int npix = p.H * p.W, nopix = p.Ho * p.Wo;
   const T* dn = dout + (size_t)n * nopix * p.o_pitch;
   const T* xn = x + (size_t)n * npix * p.x_pitch;
+  const unsigned char* sgn = reinterpret_cast<const unsigned char*>(x) + (size_t)n * npix * 8;   // SIGNW
   T* dxn = dx + (size_t)n * npix * dx_pitch;
   uint4* win = reinterpret_cast<uint4*>(smem_raw);                // [WH][WW][CVS] 16-byte units
   float4* wrow = reinterpret_cast<float4*>(smem_raw + (size_t)WH * WW * CVS * 16);   // [TH] tap weights of pooled rows oy0-1, oy0, oy0+1
@@ -509,11 +511,16 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
       tap(1, -1, wr.z * wc.x); tap(1, 0, wr.z * wc.y); tap(1, 1, wr.z * wc.z);
     }
     float xv[UE], xh[UE];
-    unpack16<T>(xraw, xv);
+    if (SIGNW) {
 #pragma unroll
-    for (int e = 0; e < UE; ++e) {
-      xh[e] = NORM ? (xv[e] - mean[e]) * rstd[e] : xv[e];
-      g[e] = xh[e] > 0.f ? g[e] : g[e] * p.slope;
+      for (int e = 0; e < UE; ++e) { xh[e] = 0.f; g[e] = ((xraw.x >> e) & 1u) ? g[e] : g[e] * p.slope; }
+    } else {
+      unpack16<T>(xraw, xv);
+#pragma unroll
+      for (int e = 0; e < UE; ++e) {
+        xh[e] = NORM ? (xv[e] - mean[e]) * rstd[e] : xv[e];
+        g[e] = xh[e] > 0.f ? g[e] : g[e] * p.slope;
+      }
     }
     if (MODE == 1) {
 #pragma unroll
@@ -540,7 +547,8 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
       yy[u] = ty0 + tp / TW; xx[u] = tx0 + tp % TW;
       const bool ok = tp < TH * TW && yy[u] < p.H && xx[u] < p.W;
       if (!ok) yy[u] = -1;
-      xr[u] = ok ? *reinterpret_cast<const uint4*>(xn + (size_t)(yy[u] * p.W + xx[u]) * p.x_pitch + cvg * UE) : make_uint4(0, 0, 0, 0);
+      if (SIGNW) xr[u] = make_uint4(ok ? sgn[(size_t)(yy[u] * p.W + xx[u]) * 8 + cvg] : 0u, 0, 0, 0);
+      else xr[u] = ok ? *reinterpret_cast<const uint4*>(xn + (size_t)(yy[u] * p.W + xx[u]) * p.x_pitch + cvg * UE) : make_uint4(0, 0, 0, 0);
     }
     // the compute phase touches LDS only; the four results stay in four separate register quads and are stored together at the
     // end: on this target a store's data VGPRs may not be rewritten before the store completes (hipcc waits vmcnt for it)
@@ -1266,6 +1274,21 @@ static hipError_t act_bwd_t(int mode, const ActParams& p, const void* dout, cons
   else if (mode == 1) act_bwd_launch<T, 1>(grid, p, dout, x, stats, part_ws, dx, use_x, dx_pitch, st);
   else act_bwd_launch<T, 2>(grid, p, dout, x, stats, rstats, dx, use_x, dx_pitch, st);
   if (red_l) return tfc_launch_part_reduce(part_ws, rstats, p.N, grid.x, red_l, st);
+  return hipGetLastError();
+}
+// mode 0, stride-2 BlurPool, 64 bf16 channels, LeakyReLU' from sign words (the conv output was never stored: tfc_first_block_fwd)
+hipError_t tfc_launch_act_pool2_bwd_signs(const ActParams& p, const void* dout, const unsigned char* sign_mask, float* rstats, void* dx, int dx_pitch,
+                                          float* part_ws, hipStream_t st) {
+  if (p.C != 64 || p.pool != 2 || (rstats && !part_ws)) return hipErrorInvalidValue;
+  const int tiles_x = (p.W + 31) / 32, tiles_y = (p.H + 15) / 16;
+  const dim3 grid(tiles_x * tiles_y, p.N, 1);
+  size_t lds = (size_t)11 * 19 * 8 * 16;
+  if (lds < 2 * 256 * 8 * sizeof(float)) lds = 2 * 256 * 8 * sizeof(float);
+  lds += (16 + 32) * 16;
+  if (rstats && !part_fits((long long)grid.x * p.N * p.C)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((tfc_act_pool2_bwd_kernel<bf16_t, 0, false, true>), grid, dim3(256), lds, st, p, (const bf16_t*)dout, (const bf16_t*)sign_mask, nullptr,
+                     rstats ? part_ws : nullptr, (bf16_t*)dx, dx_pitch, tiles_x, 64);
+  if (rstats) return tfc_launch_part_reduce(part_ws, rstats, p.N, grid.x, p.C, st);
   return hipGetLastError();
 }
 hipError_t tfc_launch_act_bwd(int dt, int mode, const ActParams& p, const void* dout, const void* x, const float* stats,

@@ -109,12 +109,12 @@ class TrainStep:
             snap_r = self.D.sn_snapshot(self.dev, True, False)
             pr = nets.on_side(self.dev, lambda: self.D.chain(real_B, real_A, snap_r, save=False), snap_r[2][0])[0]
             pr_ready = nets.side_mark(self.dev)
-            fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train, weights_only_first=True)
+            fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
             loss_trip, g_trip, (loss_fft, loss_amp, loss_pha), extra_pair = nets.on_side(self.dev, pixel_losses)
             pf, dctx_f = self.D.chain(fake, real_A, snap_f, save=True)
             nets.wait_mark(self.dev, pr_ready)                    # the logits of the real pair; the pixel losses (LPIPS: 6 ms) run on, D.backward below joins
         else:
-            fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train, weights_only_first=True)
+            fake, gctx = self.G.forward(real_A, seed=drop_seed, train=train)
             pf, dctx_f = self.D.forward(fake, real_A, power_iter=True, save=True)
             pr, _ = self.D.forward(real_B, real_A, power_iter=True, save=False)
             loss_trip, g_trip, (loss_fft, loss_amp, loss_pha), extra_pair = pixel_losses()
@@ -136,7 +136,7 @@ class TrainStep:
         else:
             g_update()
         # ---------------- discriminator step ----------------
-        (pr2, dctx_r), (pf2, dctx_f2) = self.D.forward_pair(real_B, real_A, fake, real_A, power_iter=True, save=True, weights_only=True)
+        (pr2, dctx_r), (pf2, dctx_f2) = self.D.forward_pair(real_B, real_A, fake, real_A, power_iter=True, save=True)
         g_pr, g_pf2 = self._gl(pr2), self._gl(pf2)
         loss_d = ops.bce_relativistic(dt, pr2, pf2, 1, 0.9, 0.0, da=ops.View(g_pr.t, 1, 0), db=ops.View(g_pf2.t, 1, 0))
         self.D.backward(dctx_r, g_pr, grads=self.dflat.grad_views, need_input_grad=False, accumulate=False)

@@ -172,10 +172,9 @@ class GeneratorCore:
         self._plan.run()
 
     # ---- forward ----
-    def forward(self, x, seed=0, train=True, save=True, weights_only_first=False):
-        """x: fp32 NCHW [N,3,S,S] (S multiple of 64, >= 128). Returns (fake fp32 NCHW in (-1,1), ctx). weights_only_first: the caller promises a
-        backward with need_input_grad=False (TrainStep): down1 then runs as ONE kernel (conv + LeakyReLU + BlurPool, ops.first_block_fwd) that
-        leaves only sign words for its fused backward -- its 266 MB conv output is never written."""
+    def forward(self, x, seed=0, train=True, save=True):
+        """x: fp32 NCHW [N,3,S,S] (S multiple of 64, >= 128). Returns (fake fp32 NCHW in (-1,1), ctx). down1 runs as ONE kernel (conv + LeakyReLU +
+        BlurPool, ops.first_block_fwd): its 266 MB conv output is never written, the backward needs its signs only and gets them as sign words."""
         ops.require_gpu(x)
         if not self.packed:
             self.repack()
@@ -205,7 +204,7 @@ class GeneratorCore:
             else:
                 dst = d6
             first = i == 0 and not normalize and ops.first_block_bwd_supported(dt, cin, cout)
-            if first and (weights_only_first or not save) and drop == 0.0 and getattr(self, "debug", None) is None and ops.first_block_fwd_supported():
+            if first and drop == 0.0 and getattr(self, "debug", None) is None and ops.first_block_fwd_supported():
                 ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev) if save else None
                 ops.first_block_fwd(dt, cur, cin, cout, self.packed[name]["fwd"], dst, slope=0.2, act_after_rounding=True, sign_mask=ctx.mask1)
                 ctx.raw.append(None)
@@ -333,11 +332,10 @@ class GeneratorCore:
                         hook(key)
                 _on_side(dev, _first_wgrad, g_cur)
                 continue
-            if raw is None:
-                raise ops._lib.TfcError("GeneratorUNet.backward: this forward ran with weights_only_first=True (down1's conv output was not kept); "
-                                   "need_input_grad / debug taps need a forward without it")
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
-            if normalize:
+            if raw is None:                                       # down1 of a fused forward: LeakyReLU' from the sign words
+                ops.act_bwd_signs(dt, g_cur, ctx.mask1, N, Hc, Hc, cout, d_raw, slope=0.2)
+            elif normalize:
                 rstats = ops.zeros_f32((N, cout, 2), dev)
                 ops.act_bwd(dt, 1, g_cur, raw, N, Hc, Hc, cout, None, stats=stats, slope=0.2, pool=2, drop_p=dp, seed=sd, rstats=rstats)
                 ops.act_bwd(dt, 2, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=stats, slope=0.2, pool=2, drop_p=dp, seed=sd, rstats=rstats)
@@ -397,7 +395,7 @@ class DiscriminatorCore:
                 self.head_packed[key] = buf
         self._plan.run()
 
-    def forward(self, img_a, img_b, power_iter=True, save=True, after_sn=None, weights_only=False):
+    def forward(self, img_a, img_b, power_iter=True, save=True, after_sn=None):
         """img_a, img_b: fp32 NCHW [N,3,S,S]. Returns (logits View [N,S/16,S/16,pitch 8] channel 0, ctx).
         = sn_snapshot() + chain(). after_sn: called once the power iteration of this call is queued -- everything after it reads only this call's
         snapshots of u, v, sigma, so a second forward may start from there on another stream (forward_pair)."""
@@ -405,7 +403,7 @@ class DiscriminatorCore:
         snapshot = self.sn_snapshot(img_a.device, power_iter, save)
         if after_sn is not None:
             after_sn()
-        return self.chain(img_a, img_b, snapshot, save, weights_only)
+        return self.chain(img_a, img_b, snapshot, save)
 
     def sn_snapshot(self, dev, power_iter=True, save=True):
         """one power iteration of the four spectrally normalised blocks (u, v updated in place as the reference's training-mode forward does) and this
@@ -431,10 +429,9 @@ class DiscriminatorCore:
                                                      v_snaps=vsn if save else None, ws=getattr(self, "_sn_ws", None))
         return usn, vsn, sig
 
-    def chain(self, img_a, img_b, snapshot, save=True, weights_only=False):
-        """the convolution chain of one call, given its sn_snapshot(). weights_only: the caller promises a backward with need_input_grad=False (the
-        discriminator step); block 1 then runs as one kernel (ops.first_block_fwd) and keeps sign words instead of its 266 MB conv output. A call
-        with save=False takes that kernel too."""
+    def chain(self, img_a, img_b, snapshot, save=True):
+        """the convolution chain of one call, given its sn_snapshot(). Block 1 runs as one kernel (ops.first_block_fwd) that keeps sign words
+        instead of its 266 MB conv output (all any backward reads of it)."""
         usn, vsn, sig = snapshot
         dt, dev = self.dt, img_a.device
         N, C, S, _ = img_a.shape
@@ -447,7 +444,7 @@ class DiscriminatorCore:
             sigma2 = sig[bi]
             h = cur.H
             first = bi == 0 and ops.first_block_bwd_supported(dt, cin, cout)
-            if first and (weights_only or not save) and getattr(self, "debug", None) is None and ops.first_block_fwd_supported():
+            if first and getattr(self, "debug", None) is None and ops.first_block_fwd_supported():
                 ctx.mask1 = torch.empty((N, h - 1, h - 1, 8), dtype=torch.uint8, device=dev) if save else None
                 out = new_act(N, pooled(h - 1), pooled(h - 1), cout, dt, dev)
                 ops.first_block_fwd(dt, cur, cin, cout, self.head_packed[f"f{i}"], out, bias=self.params[f"model.{i}.bias"], oscale=sigma2[1:],
@@ -478,20 +475,20 @@ class DiscriminatorCore:
         ctx.p4 = cur
         return View(logits.t, 1, 0), (ctx if save else None)
 
-    def forward_pair(self, a1, b1, a2, b2, power_iter=True, save=True, weights_only=False):
+    def forward_pair(self, a1, b1, a2, b2, power_iter=True, save=True):
         """forward(a1, b1) then forward(a2, b2), same results as the two calls in that order (the second power iteration follows the first). With the
         side stream on, the second call's convolution chain runs beside the first's: two independent chains of MFMA-bound GEMMs and HBM-bound
         blur-pools that fill each other's gaps."""
         if not _side_active() or os.environ.get("TFC_NO_FWD_PAIR", "0") not in ("", "0"):    # (A/B knob)
-            return self.forward(a1, b1, power_iter, save, None, weights_only), self.forward(a2, b2, power_iter, save, None, weights_only)
+            return self.forward(a1, b1, power_iter, save), self.forward(a2, b2, power_iter, save)
         dev = a1.device
         if not self.head_packed:
             self.repack()
         box = {}
 
         def second():
-            box["r"] = _on_side(dev, lambda: self.forward(a2, b2, power_iter, save, None, weights_only))
-        first = self.forward(a1, b1, power_iter, save, after_sn=second, weights_only=weights_only)
+            box["r"] = _on_side(dev, lambda: self.forward(a2, b2, power_iter, save))
+        first = self.forward(a1, b1, power_iter, save, after_sn=second)
         _join_side(dev)
         return first, box["r"]
 
@@ -542,11 +539,11 @@ class DiscriminatorCore:
                         hook(f"model.{i}.bias")
                 _on_side(dev, _first_wgrad, g_cur, gb_img)
                 continue
-            if raw is None:
-                raise ops._lib.TfcError("Discriminator1.backward: this forward ran with weights_only=True (block 1's conv output was not kept); "
-                                   "need_input_grad / grads=None / debug taps need a forward without it")
             d_raw = new_act(N, Hc, Hc, cout, dt, dev)
-            ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
+            if raw is None:                                       # block 1 of a fused forward: LeakyReLU' from the sign words
+                ops.act_bwd_signs(dt, g_cur, ctx.mask1, N, Hc, Hc, cout, d_raw, slope=0.2, rstats=gb_img)
+            else:
+                ops.act_bwd(dt, 0, g_cur, raw, N, Hc, Hc, cout, d_raw, stats=None, slope=0.2, pool=2, rstats=gb_img)   # + per-image bias gradient
             ddbg = getattr(self, "debug", None)
             if ddbg is not None:
                 ddbg[f"b{bi}.g_out"], ddbg[f"b{bi}.d_raw"] = g_cur, d_raw

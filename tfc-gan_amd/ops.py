@@ -302,6 +302,12 @@ def act_bwd(dt, mode, dy: View, x: View, N, H, W, C, dx: View = None, stats=None
           "tfc_act_bwd")
 
 
+def act_bwd_signs(dt, dy: View, sign_mask, N, H, W, C, dx: View, slope=0.2, rstats=None):
+    """act_bwd(mode 0, pool 2) of a first block whose conv output was never stored: LeakyReLU' from the sign words of first_block_fwd / conv_first_fwd"""
+    check(lib().tfc_act_bwd_signs(stream_ptr(), dt, dy.ptr, dy.pitch, _p(sign_mask), N, H, W, C, slope, _p(rstats), dx.ptr, dx.pitch,
+                                  part_ws(dy.t.device) if rstats is not None else None), "tfc_act_bwd_signs")
+
+
 def dropout_mask(n, drop_p, seed, device):
     out = torch.empty(n, dtype=torch.uint8, device=device)
     check(lib().tfc_dropout_mask(stream_ptr(), _p(out), n, drop_p, seed & 0xFFFFFFFF), "tfc_dropout_mask")
