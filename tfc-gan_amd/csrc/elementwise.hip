@@ -1146,12 +1146,23 @@ tfc_head_fwd_kernel(const T* __restrict__ x, int x_pitch, const float* __restric
       const int n = pix / (H * W), rem = pix - n * H * W;
       const int oy = rem / W, ox = rem - oy * W;
       float acc = 0.f;
+      // all 16 taps are requested before the first is used (clamped address; a tap outside the plane is skipped below, wave-uniformly): behind a
+      // per-tap bounds branch the loads went out one at a time and the kernel ran at 16 memory latencies per pixel (36.7 -> see DESIGN 3.1)
+      uint4 xv[16];
+      const int lc = act ? lane : 0;                               // idle lanes (C < 64 units) read lane 0's unit; their weights are zero
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        int iy = oy + (t >> 2) - 2, ix = ox + (t & 3) - 2;
+        iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        xv[t] = *reinterpret_cast<const uint4*>(x + ((size_t)(n * H + iy) * W + ix) * x_pitch + lc * UE);
+      }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int iy = oy + (t >> 2) - 2, ix = ox + (t & 3) - 2;
-        if (iy < 0 || iy >= H || ix < 0 || ix >= W || !act) continue;   // wave-uniform apart from the idle lanes
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;      // wave-uniform
         float v[UE];
-        unpack16<T>(*reinterpret_cast<const uint4*>(x + ((size_t)(n * H + iy) * W + ix) * x_pitch + lane * UE), v);
+        unpack16<T>(xv[t], v);
 #pragma unroll
         for (int e = 0; e < UE; ++e) acc += v[e] * wr[e][t];
       }
