@@ -74,7 +74,7 @@ def cpu_baseline(budget_s=8.0):
 
 PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # written by scripts/pmc_traffic.py from the two --pmc passes of THIS command
 DOMINANT_KERNEL = "tfc_igemm2_kernel"
-PROF_EVERY = 4        # instrument every 4th timed step with hipEvents (see main)
+PROF_EVERY = int(os.environ.get("TFC_BENCH_PROF_EVERY", "4"))   # instrument every 4th timed step with hipEvents (see main; the knob is for A/B runs)
 
 
 def pmc_traffic(kernel):
@@ -141,6 +141,7 @@ def main():
                          "whole-image FFT loss instead of the 16 patch FFTs)")
     args = ap.parse_args()
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")               # before the HIP runtime starts (tfc_gan_amd/__init__.py says why); inherited by self-launched ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,6 +166,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("TFC_FORCE_COLLECTIVES", "0") not in ("", "0"):
+        # one-GPU rehearsal of the RCCL path: a ONE-rank "nccl" group; every bucket all-reduce / broadcast / loss average of the product path is issued
+        # (identities in value, real in stream ordering and launch cost): `exposed_allreduce_ms` is then the floor the exchange adds at any N
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T.set_compute_dtype(cdt)
@@ -173,7 +183,8 @@ def main():
     D = T.Discriminator1((3, 256, 256)).to(dev)
     G.apply(T.weights_init_normal)
     D.apply(T.weights_init_normal)
-    ts = T.TrainStep(G, D, compute_dtype=cdt, fft_mode="patch" if args.config == "patch16" else "global")
+    bucket_kw = {"bucket_bytes": int(os.environ["TFC_BUCKET_MB"]) << 20} if os.environ.get("TFC_BUCKET_MB") else {}   # A/B knob
+    ts = T.TrainStep(G, D, compute_dtype=cdt, fft_mode="patch" if args.config == "patch16" else "global", **bucket_kw)
     A, B = T.synthetic_pairs(args.batch, seed=1234 + rank)      # the product's own recipe: oracle/ is used by the checker legs only
     A, B = A.to(dev), B.to(dev)
 
@@ -200,7 +211,8 @@ def main():
     # The roofline object is measured live, inside the timed region, with hipEvent pairs around the MFMA kernel launches on the launch
     # stream. An event pair costs ~2.3 us of stream time (A/B in scripts/ab_prof.py: 0.45 ms per fully instrumented step, 3.5 %), so
     # every PROF_EVERY-th timed step is instrumented, not all of them: `value` then carries < 1 % of instrumentation overhead.
-    parallel.exposed_wait_begin()                          # hipEvent pairs around the waits of BucketReducer.finish(): `exposed_allreduce_ms`
+    if os.environ.get("TFC_BENCH_NO_EXPOSED", "0") in ("", "0"):   # (A/B knob: what does the measurement itself cost?)
+        parallel.exposed_wait_begin()                      # hipEvent pairs around the waits of BucketReducer.finish(): `exposed_allreduce_ms`
     t0 = time.perf_counter()
     # The product runs its weight gradients on a second stream beside the input-gradient chain (nets.py). A launch that shares the chip with another
     # kernel has no duration of its own, so the INSTRUMENTED steps (and only they) run everything in line on one stream: the roofline object then
@@ -274,7 +286,7 @@ def main():
             # stream time between "all buckets issued" and "all buckets arrived" in BucketReducer.finish(), summed over the generator's and the
             # discriminator's exchange, max over ranks (DESIGN section 6 predicts 0.09-0.18 ms at 8 GPUs; the generator's part sits on the side stream
             # beside the discriminator step, so this is an upper bound of what the exchange adds to the step)
-            "exposed_allreduce_ms": exposed_ms, "allreduce_backend": (dist.get_backend() if world > 1 else None),
+            "exposed_allreduce_ms": exposed_ms, "allreduce_backend": (dist.get_backend() if parallel.collectives_active() else None),
             "final_losses": {"loss_G": loss_g, "loss_D": loss_d},
         }
         if world == 1 and not args.lpips and not args.no_cpu_baseline and args.dtype == "bf16":
@@ -300,6 +312,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

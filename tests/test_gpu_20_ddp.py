@@ -46,6 +46,26 @@ def test_two_ranks_match_one_rank(tmp_path):
         assert frac <= 2e-2, (k, frac)
 
 
+def test_two_stream_step_under_a_real_one_rank_rccl_group(tmp_path):
+    """The product default on several GPUs -- RCCL + the side stream -- with the REAL ProcessGroupNCCL on the one card there is: a one-rank group of
+    backend "nccl" with TFC_FORCE_COLLECTIVES=1, so that every bucket all-reduce (issued from backward hooks that fire on the side stream), the weight
+    broadcasts and the loss average go through RCCL's stream hand-over (its communication stream waits for the stream current at the call; `work.wait()`
+    orders the stream current at the wait behind it). With one rank the sums are identities, and every reduction of the library has a fixed order: the
+    weights, Adam moments, spectral-norm vectors and losses after two steps must be BIT-EQUAL to the run without a process group. What this cannot show
+    is bandwidth or a second rank's data; what it does show is that the stream ordering of the product path under RCCL is sound on hardware."""
+    plain, rccl = str(tmp_path / "plain.pt"), str(tmp_path / "rccl.pt")
+    worker = os.path.join(ROOT, "tests", "rccl_world1_worker.py")
+    env = dict(os.environ, TFC_TEST_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFC_FORCE_COLLECTIVES", "TFC_WGRAD_STREAM"):
+        env.pop(k, None)
+    subprocess.run([sys.executable, worker, plain, "plain"], check=True, env=env, timeout=300)
+    subprocess.run([sys.executable, worker, rccl, "rccl"], check=True, env=env, timeout=300)
+    a, b = torch.load(plain, weights_only=True), torch.load(rccl, weights_only=True)
+    assert int(b["collectives"]) >= 2 * (6 + 2), int(b["collectives"])          # 6 generator + 2 discriminator buckets per step (+ the loss averages)
+    for k in ("g", "d", "gm", "dm", "sn", "loss"):
+        assert torch.equal(a[k], b[k]), (k, (a[k].double() - b[k].double()).abs().max().item())
+
+
 def test_two_stream_step_under_stream_ordered_collectives(monkeypatch):
     """the product default on several GPUs is RCCL + the side stream -- bucket all-reduces are issued from backward hooks that fire
     ON the side stream, `g_reduce.finish()` + Adam + re-pack run there beside the discriminator step, and engine.step does partial joins; every
@@ -106,6 +126,7 @@ def test_two_stream_step_under_stream_ordered_collectives(monkeypatch):
         T.set_wgrad_stream(True)
         assert nets.side_stream_on()
         monkeypatch.setattr(parallel, "world_size", lambda: 2)
+        monkeypatch.setattr(parallel, "collectives_active", lambda: True)
         monkeypatch.setattr(parallel.dist, "all_reduce", fake_all_reduce)
         monkeypatch.setattr(parallel.dist, "broadcast", lambda *a, **k: None)
         ddp = run(True)

@@ -7,6 +7,14 @@ Reference surface mirrored here (TFC-GAN-FFT/TFCGAN_multigpu_patchFFT_16P.py): U
 Discriminator1 (alias Discriminator), weights_init_normal, make_16_patches, the 16-patch triplet head (ContrastiveLoss),
 FFT_Components / fft_components / calculate_ffts, and the fused TrainStep + data-parallel layer.
 """
+import os as _os
+
+# The step runs on two HIP streams (nets.py) and, with several GPUs, beside RCCL's stream. ROCm maps a process's streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4): with a process group alive the side stream came to share a hardware queue with busy work and the two-stream step ran 1.0 ms (10 %)
+# SLOWER than without collectives -- measured with a one-rank "nccl" group, DESIGN.md section 6; 8 queues bring it back to +0.2 ms. The runtime reads the
+# variable when it initialises (first GPU call), so it is set here, before anything of this package touches the GPU; an explicit setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from . import _lib, data, engine, inference, losses, lpips, models, nets, ops, parallel, stn, stn21, synthetic  # noqa: F401
 from ._lib import TfcError, build  # noqa: F401
 from .engine import TrainStep  # noqa: F401

@@ -160,7 +160,7 @@ class TrainStep:
             self.last["loss_temp_g"] = loss_temp
         if extra is not None:
             self.last["loss_extra_g"] = extra.reshape(())
-        if parallel.world_size() > 1:                             # every logged loss is a batch mean: mean over ranks = the global-batch value
+        if parallel.collectives_active():                          # every logged loss is a batch mean: mean over ranks = the global-batch value
             keys = [k for k in self.last if k != "fake_B"]
             packed = torch.stack([self.last[k].reshape(()).float() for k in keys])
             parallel.all_reduce_mean(packed)

@@ -8,6 +8,8 @@ backward pass finalises gradients so that each bucket's all-reduce overlaps the 
 
 Backend-agnostic (tested with gloo on CPU tensors, world size 2).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,6 +24,13 @@ def world_size():
 
 def rank():
     return dist.get_rank() if dist_ready() else 0
+
+
+def collectives_active():
+    """issue the gradient / loss / weight collectives? Yes with more than one rank -- and, for the one-GPU rehearsal of the product default (RCCL +
+    the side stream), in a ONE-rank group under TFC_FORCE_COLLECTIVES=1: the all-reduces are then identities, but they travel through
+    ProcessGroupNCCL's stream hand-over exactly as with eight ranks (tests/test_gpu_20_ddp.py: bit-equal to the run without a group)."""
+    return dist_ready() and (dist.get_world_size() > 1 or os.environ.get("TFC_FORCE_COLLECTIVES", "0") not in ("", "0"))
 
 
 # ---- measurement: how long a stream waits for gradient buckets (bench.py: exposed_allreduce_ms) -------------------------------------------
@@ -102,7 +111,7 @@ class BucketReducer:
 
     def ready(self, name):
         """gradient `name` is final (call in backward order)."""
-        if world_size() == 1:
+        if not collectives_active():
             return
         i = self.bucket_of[name]
         self.pending[i].discard(name)
@@ -114,7 +123,7 @@ class BucketReducer:
         """wait for every bucket (flushing buckets whose hooks never fired); returns the factor that turns the summed
         gradient into the mean (folded into the Adam kernel, so no extra pass over the gradients)."""
         ws = world_size()
-        if ws > 1:
+        if collectives_active():
             for i, p in enumerate(self.pending):
                 if p:
                     s, e, _ = self.buckets[i]
@@ -137,19 +146,19 @@ class BucketReducer:
 def all_reduce_mean(t, group=None):
     """in-place mean over the ranks of a small tensor (the logged losses: one collective of ~10 floats per step)"""
     ws = world_size()
-    if ws > 1:
+    if collectives_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         t /= ws
     return t
 
 
 def broadcast_flat(flat: FlatParams, src=0, group=None):
-    if world_size() > 1:
+    if collectives_active():
         dist.broadcast(flat.data, src=src, group=group)
 
 
 def broadcast_tensors(tensors, src=0, group=None):
-    if world_size() > 1:
+    if collectives_active():
         for t in tensors:
             dist.broadcast(t, src=src, group=group)
 
