@@ -15,10 +15,15 @@ from tfc_gan_amd import parallel, stn21  # noqa: E402
 
 def run(out_path, global_batch=2):
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        dist.init_process_group("gloo")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    rccl1 = world == 1 and os.environ.get("TFC_TEST_RCCL1", "0") == "1"      # one-rank "nccl" group: the collectives are issued through RCCL, moving nothing
+    if world > 1:
+        dist.init_process_group("gloo")
+    elif rccl1:
+        os.environ["TFC_FORCE_COLLECTIVES"] = "1"
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{os.environ['TFC_TEST_PORT']}", rank=0, world_size=1)
+        assert parallel.collectives_active()
     T.set_compute_dtype(torch.float32)
     torch.manual_seed(1)
     st = stn21.STN21Step((3, 256, 256), lpips=None, device=dev, bucket_bytes=64 << 20)
@@ -37,6 +42,7 @@ def run(out_path, global_batch=2):
                     "losses": torch.stack([out[k].float().reshape(()) for k in ("loss_G", "loss_GAN", "recon_loss", "morph_loss", "loss_D")]).cpu()}, out_path)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

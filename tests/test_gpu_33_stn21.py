@@ -194,6 +194,30 @@ def test_stn21_batch32_bf16_properties():
 
 
 
+def test_stn21_step_under_a_real_one_rank_rccl_group(tmp_path):
+    """STN21Step's exchange (post-accumulate hooks -> bucket all-reduces -> tfc_adam_step) through the real ProcessGroupNCCL in a one-rank group
+    (TFC_FORCE_COLLECTIVES=1): the sums are identities, so the step must end bit-equal to the run without a process group"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "stn21_ddp_worker.py")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    one, two = str(tmp_path / "plain.pt"), str(tmp_path / "rccl.pt")
+    env = dict(os.environ, TFC_TEST_PORT=str(port))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFC_FORCE_COLLECTIVES", "TFC_TEST_RCCL1"):
+        env.pop(k, None)
+    subprocess.run([sys.executable, worker, one], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, worker, two], check=True, env=dict(env, TFC_TEST_RCCL1="1"), timeout=600)
+    a, b = torch.load(one, weights_only=True), torch.load(two, weights_only=True)
+    for k in ("losses", "gg", "dg", "g", "d"):
+        assert torch.equal(a[k], b[k]), (k, (a[k].double() - b[k].double()).abs().max().item())
+
+
 def test_stn21_two_ranks_match_one_rank(tmp_path):
     """configuration C5 is an 8-GPU configuration (BASELINE.json configs[4]): STN21Step shards the batch over one process per GPU with the same flat
     buffers + bucketed all-reduce as the PATCH-16 engine. Two ranks (sharing the one card, gloo), each stepping one image of a global batch of 2, must
