@@ -25,8 +25,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 // Measured on the implicit-GEMM epilogue: -20..28 % kernel time.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_stream16(void* p, const uint4& v) {
+#ifdef TFC_NO_STREAM_STORES                                       // A/B build (scripts/build_variant.sh): plain stores
+  *reinterpret_cast<uint4*>(p) = v;
+#else
   u32x4_t vv = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(vv, reinterpret_cast<u32x4_t*>(p));
+#endif
 }
 __device__ __forceinline__ uint4 load_stream16(const void* p) {
   const u32x4_t vv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
