@@ -136,9 +136,11 @@ def main():
                     help="bf16 = the benchmarked arithmetic (BASELINE.json); fp32 = the exact-fp32 parity mode (generator L1 vs oracle 1.9e-6), on the "
                          "legacy one-tile-per-workgroup kernels at 1/16 of the MFMA rate -- reported so that its cost is a number, not a guess")
     ap.add_argument("--lpips", action="store_true", help="include the LPIPS term (P16:598) in the timed step (seeded-random VGG16 weights)")
-    ap.add_argument("--config", choices=["patch16", "glo16"], default="patch16",
+    ap.add_argument("--config", choices=["patch16", "glo16", "stn21"], default="patch16",
                     help="patch16 = BASELINE.json configs[1] (the metric's configuration); glo16 = configs[2] (TFCGAN_multigpu_globalFFT_16P.py: "
-                         "whole-image FFT loss instead of the 16 patch FFTs)")
+                         "whole-image FFT loss instead of the 16 patch FFTs); stn21 = configs[4] "
+                         "(TFCGAN_STN21_Original_NewModel3_Official.py: two generators, two discriminators, localiser + warp, LPIPS with seeded-random VGG16 "
+                         "weights, morphological triplet; tfc_gan_amd.STN21Step)")
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")               # before the HIP runtime starts (tfc_gan_amd/__init__.py says why); inherited by self-launched ranks
@@ -184,7 +186,17 @@ def main():
     G.apply(T.weights_init_normal)
     D.apply(T.weights_init_normal)
     bucket_kw = {"bucket_bytes": int(os.environ["TFC_BUCKET_MB"]) << 20} if os.environ.get("TFC_BUCKET_MB") else {}   # A/B knob
-    ts = T.TrainStep(G, D, compute_dtype=cdt, fft_mode="patch" if args.config == "patch16" else "global", **bucket_kw)
+    stn = args.config == "stn21"
+    if stn:
+        import warnings
+        assert not args.lpips, "--config stn21 always carries the LPIPS term (STN:640)"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                       # "seeded-random weights" -- stated in config.workload
+            stn_crit = T.LPIPS().to(dev)
+        del G, D
+        ts = T.STN21Step((3, 256, 256), lpips=stn_crit, device=dev, **bucket_kw)
+    else:
+        ts = T.TrainStep(G, D, compute_dtype=cdt, fft_mode="patch" if args.config == "patch16" else "global", **bucket_kw)
     A, B = T.synthetic_pairs(args.batch, seed=1234 + rank)      # the product's own recipe: oracle/ is used by the checker legs only
     A, B = A.to(dev), B.to(dev)
 
@@ -205,8 +217,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_step():
+        return ts.step(A, B) if stn else ts.step(A, B, extra_loss_G=extra)
+
     for _ in range(args.warmup):
-        ts.step(A, B, extra_loss_G=extra)
+        run_step()
     barrier()
     # The roofline object is measured live, inside the timed region, with hipEvent pairs around the MFMA kernel launches on the launch
     # stream. An event pair costs ~2.3 us of stream time (A/B in scripts/ab_prof.py: 0.45 ms per fully instrumented step, 3.5 %), so
@@ -223,7 +238,7 @@ def main():
         inst = i % PROF_EVERY == 0
         T.ops.prof_enable(inst)
         T.set_wgrad_stream(side_default and not inst)
-        out = ts.step(A, B, extra_loss_G=extra)
+        out = run_step()
     barrier()
     elapsed = time.perf_counter() - t0
     T.ops.prof_enable(False)
@@ -256,18 +271,22 @@ def main():
         nprof = len(range(0, args.steps, PROF_EVERY))                       # timed steps that carried the hipEvent instrumentation
         step_s = elapsed / args.steps
         line = {
-            "metric": "training images/sec at 256x256 PATCH-16, 1/2/4/8 MI355X; gen L1 vs ref",
+            "metric": ("training images/sec at 256x256 STN21_Original_NewModel3_Official (BASELINE.json configs[4]; not the headline metric)" if stn else
+                       "training images/sec at 256x256 PATCH-16, 1/2/4/8 MI355X; gen L1 vs ref"),
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (("PATCH-16 256x256 " + args.dtype + ", batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
+            "config": {"workload": ("STN21_Original_NewModel3_Official 256x256 " + args.dtype + ", batch 32 per GPU (BASELINE.json configs[4]): localiser + affine warp, two "
+                                    "generators, two discriminators, morphological triplet, 0.5 * LPIPS with seeded-random VGG16 weights (same work, not the "
+                                    "published metric), Adam on flat buffers (STN:609-672)") if stn else
+                                   (("PATCH-16 256x256 " + args.dtype + ", batch 32 per GPU (BASELINE.json configs[1]; configs[3] at 8 GPUs): "
                                      "G step + D step, 16-patch triplet + patch-FFT loss, Adam") if args.config == "patch16" else
                                     ("GLO-16 (TFCGAN_multigpu_globalFFT_16P.py) 256x256 " + args.dtype + ", batch 32 per GPU (BASELINE.json configs[2]): "
                                      "G step + D step, 16-patch triplet + whole-image FFT loss, Adam")) +
                                    (" + 0.5 * LPIPS(fake_B, real_B) (P16:598, seeded-random VGG16 weights: same work, not the published metric)" if args.lpips else
                                     " (step as BASELINE.md section 3 defines it: LPIPS and the temperature head excluded)"),
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
-                       "algorithmic_gflop_per_image": T.TrainStep.STEP_GFLOP},
+                       "algorithmic_gflop_per_image": None if stn else T.TrainStep.STEP_GFLOP},
             "roofline": {"bound": "mfma", "kernel": kname + (" (persistent halo-staged implicit-GEMM conv: fwd / dgrad / convT / upconv, bf16 MFMA 32x32x16)" if args.dtype == "bf16"
                                                              else " (one-tile-per-workgroup halo-staged implicit GEMM, fp32 MFMA 32x32x2: exact fp32 parity mode)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -282,14 +301,14 @@ def main():
                                            "unit": "TFLOP/s", "launches": wg_n, "share_of_step_time": (wg_ms / 1e3 / nprof) / step_s},
                          "fused_first_block_backward": {"kernel": "tfc_wgrad_c8_fusedm_kernel (transposed blur as a GEMM on the matrix core + first-layer weight gradient; sign words instead of the stored activation)",
                                                         "calls": fb_n, "avg_call_ms": fb_ms / max(fb_n, 1), "share_of_step_time": (fb_ms / 1e3 / nprof) / step_s}},
-            "whole_step_tflops": T.TrainStep.STEP_GFLOP * value / 1e3,
+            "whole_step_tflops": None if stn else T.TrainStep.STEP_GFLOP * value / 1e3,
             # stream time between "all buckets issued" and "all buckets arrived" in BucketReducer.finish(), summed over the generator's and the
             # discriminator's exchange, max over ranks (DESIGN section 6 predicts 0.09-0.18 ms at 8 GPUs; the generator's part sits on the side stream
             # beside the discriminator step, so this is an upper bound of what the exchange adds to the step)
             "exposed_allreduce_ms": exposed_ms, "allreduce_backend": (dist.get_backend() if parallel.collectives_active() else None),
             "final_losses": {"loss_G": loss_g, "loss_D": loss_d},
         }
-        if world == 1 and not args.lpips and not args.no_cpu_baseline and args.dtype == "bf16":
+        if world == 1 and not stn and not args.lpips and not args.no_cpu_baseline and args.dtype == "bf16":
             # the reference's full loss_G also carries 0.5 * LPIPS (P16:598, :607): the same step with that term, timed right after
             crit = make_lpips()
             term = crit.as_extra_loss(0.5)
@@ -304,11 +323,11 @@ def main():
             dt2 = time.perf_counter() - t1
             line["with_lpips"] = {"value": args.batch * k2 / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2 / k2, "steps": k2,
                                   "note": "same step + 0.5 * LPIPS(fake_B, real_B): VGG16 forward x2 + backward w.r.t. fake_B, seeded-random weights"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stn:
             line["generator_l1_vs_oracle"] = generator_l1(dev)
             line["cpu_baseline"] = cpu_baseline()
         else:
-            line["cpu_baseline"] = None
+            line["cpu_baseline"] = None                           # (stn21: the CPU port in oracle/ is the PATCH-16 / GLO-16 step)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

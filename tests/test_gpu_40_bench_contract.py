@@ -41,6 +41,21 @@ def test_bench_glo16_and_fp32_modes_run():
     assert f["dtype"] == "fp32" and f["roofline"]["peak"] == 157.3 and 0 < f["roofline"]["frac"] < 1
 
 
+def test_bench_stn21_config_and_one_rank_rccl_mode_run():
+    """`--config stn21` (BASELINE.json configs[4] on the same line format) and the one-GPU rehearsal of the RCCL path (TFC_FORCE_COLLECTIVES=1: a one-rank
+    "nccl" group created by bench.py itself; the collectives are issued and `exposed_allreduce_ms` is measured)"""
+    s = _run("--no-cpu-baseline", "--config", "stn21", "--batch", "2")
+    assert "STN21" in s["config"]["workload"] and s["value"] > 0 and s["cpu_baseline"] is None and s["roofline"]["launches"] > 0
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"]
+    env = dict(os.environ, TFC_FORCE_COLLECTIVES="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["allreduce_backend"] == "nccl" and d["exposed_allreduce_ms"] > 0.0
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus N` (no outer launcher) must start its N ranks itself and print ONE line with n_gpus = N. Rehearsed on
     the one card with gloo (TFC_BENCH_BACKEND=gloo: both ranks share cuda:0); on a multi-GPU node the same command runs over RCCL."""
