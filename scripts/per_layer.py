@@ -17,7 +17,7 @@ import sys
 
 PEAK = 2500.0
 CONV_KERNELS = ("tfc_igemm_kernel", "tfc_conv_c8_kernel", "tfc_upconv_head_kernel", "tfc_dgrad_rows4_kernel", "tfc_wgrad_kernel", "tfc_wgrad22_kernel",
-                "tfc_wgradT_kernel", "tfc_wgrad_reduce_kernel", "tfc_wgrad_finish_kernel", "tfc_igemm2_kernel", "tfc_wgrad_fin_kernel", "tfc_wgrad_reduce_fin_kernel", "tfc_wgrad_c8_kernel", "tfc_wgrad_c8_reduce_kernel", "tfc_wgrad_head_kernel", "tfc_wgrad_head_reduce_kernel", "tfc_wgrad_c8_fused_kernel", "tfc_wgrad_c8_fusedm_kernel",
+                "tfc_wgradT_kernel", "tfc_wgradT2_kernel", "tfc_wgrad_reduce_kernel", "tfc_wgrad_finish_kernel", "tfc_igemm2_kernel", "tfc_wgrad_fin_kernel", "tfc_wgrad_reduce_fin_kernel", "tfc_wgrad_c8_kernel", "tfc_wgrad_c8_reduce_kernel", "tfc_wgrad_head_kernel", "tfc_wgrad_head_reduce_kernel", "tfc_wgrad_c8_fused_kernel", "tfc_wgrad_c8_fusedm_kernel",
                 "tfc_wgrad_head_finish_kernel", "tfc_dgrad_head_kernel", "tfc_first_block_fwd_kernel")
 OPN = {0: "conv", 1: "padconv", 2: "convT", 3: "upconv"}
 PASSN = {0: "fwd", 1: "dgrad", 2: "wgrad", 3: "wgrad-finish"}

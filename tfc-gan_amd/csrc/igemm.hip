@@ -2891,6 +2891,153 @@ tfc_wgradT_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Round 3: the same transposed-convolution weight gradient with a 32 n x 64 c workgroup tile. tfc_wgradT_kernel<false> is bound by operand re-streaming:
+// a 32 x 32 tile re-reads dy Cin/32 times and x Cout/32 times from L2 (670 MB per launch at 256 -> 64 @ 64^2, 6.7 TB/s at 100 us) and issues six
+// transposing LDS reads per four MFMAs. Here wave w = phase still owns its 2 x 2 taps, but for TWO 32-channel halves of x: eight accumulator tiles per wave
+// (128 VGPRs), one A fragment serves eight MFMAs, dy is streamed Cin/64 times. Two workgroups per CU (55 KB of LDS). The slabs keep the logical numbering
+// of the 32 x 32 kernel (pair = nb * ncb + cb, cb = 2 cb2 + half), so the reduce kernels are unchanged.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tfc_wgradT2_kernel(const bf16_t* __restrict__ x, int IH, int IW, int x_pitch, int Cin_pad, const bf16_t* __restrict__ dy, int dy_pitch,
+                   int Nn_pad, int nimg, float4* slab, int nbw, int ncb, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROWB = 64;
+  constexpr int HH = TFC_TILE_H + 2, HW = TFC_TILE_W + 2;
+  constexpr int DO_BYTES = 4 * 128 * ROWB;                       // [phase][px][32 n]
+  constexpr int HPLANE = HH * HW * ROWB;                         // one 32-channel half of the halo
+  constexpr int NDO = DO_BYTES / 16 / 256, NHA = (HH * HW * 8 + 255) / 256;   // 8 and 6 units per thread
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int py = wave >> 1, px = wave & 1;
+  const int OH = 2 * IH, OW = 2 * IW;
+  const int tiles_y = (IH + TFC_TILE_H - 1) / TFC_TILE_H, tiles_x = (IW + TFC_TILE_W - 1) / TFC_TILE_W;
+  const int ntiles = nimg * tiles_y * tiles_x;
+  const int ncb2 = ncb >> 1;
+
+  const int bid = tfc_xcd_remap(blockIdx.x, gridDim.x);
+  const int pair2 = bid % (nbw * ncb2);
+  const int sp = bid / (nbw * ncb2);
+  const int cb2 = pair2 % ncb2, nb = pair2 / ncb2;
+
+  f32x16_t acc[8];                                               // [half][row offset][column offset]
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
+
+  uint4 vdo[NDO], vha[NHA];
+  auto tile_load = [&](int tl) {
+    int t = tl;
+    const int txb = t % tiles_x; t /= tiles_x;
+    const int tyb = t % tiles_y;
+    const int img = t / tiles_y;
+    const int a0 = tyb * TFC_TILE_H, b0 = txb * TFC_TILE_W;
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) {
+      const int idx = tid + i * 256;                             // ((phase * 128) + pixel) * 4 + g
+      const int g = idx & 3, pxl = (idx >> 2) & 127, ph = idx >> 9;
+      const int a = a0 + (pxl >> 4), b = b0 + (pxl & 15);
+      const int n0 = nb * 32 + g * 8;
+      vdo[i] = make_uint4(0, 0, 0, 0);
+      if (a < IH && b < IW && n0 < Nn_pad)
+        vdo[i] = *reinterpret_cast<const uint4*>(dy + ((size_t)(img * OH + 2 * a + (ph >> 1)) * OW + 2 * b + (ph & 1)) * dy_pitch + n0);
+    }
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;                             // (pixel * 2 + half) * 4 + g: a pixel's 128 bytes are one contiguous run
+      vha[i] = make_uint4(0, 0, 0, 0);
+      if (idx < HH * HW * 8) {
+        const int g = idx & 3, hc = (idx >> 2) & 1, pix = idx >> 3;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int y = a0 - 1 + hy, xx = b0 - 1 + hx;
+        const int c0 = (2 * cb2 + hc) * 32 + g * 8;
+        if (y >= 0 && y < IH && xx >= 0 && xx < IW && c0 < Cin_pad)
+          vha[i] = *reinterpret_cast<const uint4*>(x + ((size_t)(img * IH + y) * IW + xx) * x_pitch + c0);
+      }
+    }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NDO; ++i) *reinterpret_cast<uint4*>(smem + (tid + i * 256) * 16) = vdo[i];
+#pragma unroll
+    for (int i = 0; i < NHA; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < HH * HW * 8) {
+        const int g = idx & 3, hc = (idx >> 2) & 1, pix = idx >> 3;
+        *reinterpret_cast<uint4*>(smem + DO_BYTES + hc * HPLANE + (pix * 4 + g) * 16) = vha[i];
+      }
+    }
+  };
+
+  const int grp = lane >> 4, li = lane & 15;
+  const int cb16 = grp & 1, hk = grp >> 1, q = li >> 2, p = li & 3;
+  const int trLane = (8 * hk + q) * ROWB + cb16 * 32 + p * 8;
+  auto tr16 = [&](const unsigned char* p0) {
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4_t, p0 + 4 * ROWB));
+    uint4 r;
+    r.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    r.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    r.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    r.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return r;
+  };
+  constexpr int rowb = HW * ROWB;
+  auto compute = [&]() {
+    const unsigned char* acol = smem + wave * 128 * ROWB + trLane;
+    const unsigned char* hcol = smem + DO_BYTES + (py * HW + px) * ROWB + trLane;    // halo row kt + py + r, column shift px + c (filter tap jy = 1 - r, jx = 1 - c)
+    uint4 rw[2][2][2];                                           // [half][window row][column]
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) rw[hc][0][c] = tr16(hcol + hc * HPLANE + c * ROWB);
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) rw[hc][1][c] = tr16(hcol + hc * HPLANE + (kt + 1) * rowb + c * ROWB);
+      const bf16x8_t av = __builtin_bit_cast(bf16x8_t, tr16(acol + kt * 16 * ROWB));
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            acc[hc * 4 + r * 2 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8_t, rw[hc][r][c]), acc[hc * 4 + r * 2 + c], 0, 0, 0);
+#pragma unroll
+      for (int hc = 0; hc < 2; ++hc)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) rw[hc][0][c] = rw[hc][1][c];
+    }
+  };
+
+  int tl = sp;
+  if (tl < ntiles) { tile_load(tl); tile_store(); }
+  __syncthreads();
+  for (; tl < ntiles; tl += nsplit) {
+    const bool more = (tl + nsplit) < ntiles;
+    if (more) tile_load(tl + nsplit);                            // next tile -> registers while this one is multiplied
+    compute();
+    __syncthreads();                                             // single LDS image: everyone is done reading it
+    if (more) tile_store();
+    __syncthreads();
+  }
+  // slabs in the numbering of the 32 x 32 kernel: logical workgroup (sp, nb, cb = 2 cb2 + half)
+#pragma unroll
+  for (int hc = 0; hc < 2; ++hc) {
+    const int lbid = sp * (nbw * ncb) + nb * ncb + 2 * cb2 + hc;
+    float4* ps = slab + ((size_t)lbid * 4 + wave) * (4 * 4 * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        ps[(a * 4 + q4) * 64] = make_float4(acc[hc * 4 + a][4 * q4], acc[hc * 4 + a][4 * q4 + 1], acc[hc * 4 + a][4 * q4 + 2], acc[hc * 4 + a][4 * q4 + 3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Weight gradient of the generator head (Upsample x2 -> ZeroPad -> Conv2d(128, C <= 8, 4); P16:150-157), bf16. tfc_wgradT_kernel<true> spends a
 // 32-row MFMA tile on the 3 (padded: 8) output channels of ONE sub-pixel phase per wave: 4.7 M MFMAs, 147 us, MFMA-bound on padding. Here the four
 // phases x 8 padded channels ARE the 32 rows (row = phase * 8 + oc): dy of a tile is staged as [input-grid pixel][py][px][oc8] = 64 bytes per
@@ -3992,6 +4139,16 @@ bool tfc_launch_wgrad_phases_fused(int up, const void* x, int N, int IH, int IW,
       TFC_LAUNCH(tfc_wgrad_reduce_kernel, dim3(nbw * ncb * T * 4), dim3(256), 0, st, (const float4*)slab, dwacc, none, 3, T, nsplit,
                          nbw * ncb, ncb, Cout, Cin, wv);
   } else {
+    static const bool narrow = [] { const char* e = getenv("TFC_WGRADT_NARROW"); return e && atoi(e) != 0; }();   // A/B knob: the 32 x 32 workgroup tile
+    if (!narrow && ncb % 2 == 0 && ncb >= 2) {                    // 32 n x 64 c tiles, 2 workgroups per CU
+      int ns2 = 512 / (nbw * (ncb / 2));                           // (256 / 384 workgroups measured 8-9 % slower)
+      if ((size_t)nbw * ncb * ns2 * blk_bytes > budget) ns2 = (int)(budget / ((size_t)nbw * ncb * blk_bytes));
+      if (ns2 > ntiles) ns2 = ntiles;
+      if (ns2 < 1) ns2 = 1;
+      nsplit = ns2;
+      TFC_LAUNCH(tfc_wgradT2_kernel, dim3(nbw * (ncb / 2) * nsplit), dim3(256), 4 * 128 * 64 + 2 * (TFC_TILE_H + 2) * (TFC_TILE_W + 2) * 64, st, (const bf16_t*)x, IH, IW,
+                 x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch, Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
+    } else
     TFC_LAUNCH(tfc_wgradT_kernel<false>, grid, dim3(256), lds, st, (const bf16_t*)x, IH, IW, x_pitch, Cin_pad, (const bf16_t*)dy, dy_pitch,
                        Nn_pad, N, (float4*)slab, nbw, ncb, nsplit);
     if (tfc_fin_eligible(fin, nbw * ncb, 4)) {
