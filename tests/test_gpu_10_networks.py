@@ -455,6 +455,58 @@ class _EngineStatsNorm(torch.autograd.Function):
         return r * (g - mg - xh * mgx), None, None
 
 
+@pytest.mark.parametrize("net", ["generator", "discriminator"])
+def test_fused_first_block_forward_vs_storage_oracle(net):
+    """The per-layer tests below run with debug taps, i.e. on the UNFUSED first block; the product runs tfc_first_block_fwd (conv + LeakyReLU + BlurPool in one
+    kernel, the conv output never stored). Here that kernel itself is held against the oracle's bf16-storage model of the block: the pooled output within the
+    forward bound of the per-layer tests (5e-4 rel-L2), and its sign words against the sign of the oracle's own (bf16-rounded) conv output -- they may differ
+    only where the two fp32 summation orders round a value across zero (none observed; a handful allowed). Generator form: LeakyReLU after the rounding of
+    the raw conv output (P16:105-109); discriminator form: bias, 1/sigma and LeakyReLU before it (P16:187-190)."""
+    from tfc_gan_amd import ops
+    T.set_compute_dtype(torch.bfloat16)
+    torch.set_num_threads(16)
+    dt = ops.DT_BF16
+    N, S = 2, 256
+    A, B = O.synthetic_pairs(N, seed=71)
+    rb, rw = O._RoundBoth.apply, O._RoundFwd.apply
+    if net == "generator":
+        Gc = O.init_weights_portable(O.GeneratorUNet((3, S, S)), seed=61).eval()
+        w = Gc.down1.model[0].weight.detach()
+        x = O._bf(A)
+        cin, bias, inv_sigma = 3, None, None
+        with torch.no_grad():
+            z = rb(F.conv2d(x, rw(w), padding=1))
+            want = rb(O._blur(F.leaky_relu(z, 0.2), 2))
+        xin = ops.pack_nhwc8(dt, A.to(DEV))
+    else:
+        Dc = O.init_weights_portable(O.Discriminator1((3, S, S)), seed=62).train()
+        w = Dc.model[0].parametrizations.weight.original.detach()
+        bias = Dc.model[0].bias.detach()
+        inv_sigma = 0.37                                            # any positive scale: the kernel takes 1/sigma as a device scalar
+        x = O._bf(torch.cat((A, B), 1))
+        cin = 6
+        with torch.no_grad():
+            z = rb(F.leaky_relu(F.conv2d(x, rw(w), padding=1) * inv_sigma + bias.view(1, -1, 1, 1), 0.2))
+            want = rb(O._blur(z, 2))
+        xin = ops.pack_nhwc8(dt, A.to(DEV), B.to(DEV))
+    pk = ops.pack_weight(dt, ops.OP_CONV, 0, w.to(DEV), cin, 64)
+    Po = want.shape[2]
+    got = ops.new_act(N, Po, Po, 64, dt, DEV)
+    mask = torch.zeros((N, S - 1, S - 1, 8), dtype=torch.uint8, device=DEV)
+    ops.first_block_fwd(dt, xin, cin, 64, pk, got, bias=None if bias is None else bias.to(DEV),
+                        oscale=None if inv_sigma is None else torch.tensor([inv_sigma], device=DEV), slope=0.2, act_after_rounding=(net == "generator"),
+                        sign_mask=mask)
+    torch.cuda.synchronize()
+    r = _rel(_nchw(got), want)
+    print(f"  {net} first block (fused forward) rel-L2 {r:.3e}")
+    assert r <= 5e-4, r
+    bits = np.unpackbits(mask.cpu().numpy().reshape(N, S - 1, S - 1, 8), axis=3, bitorder="little")       # bit c of the pixel's 64-bit word = channel c
+    want_bits = (z > 0).permute(0, 2, 3, 1).numpy().astype(np.uint8)
+    nbad = int((bits != want_bits).sum())
+    print(f"  sign words: {nbad} of {bits.size} bits differ from the oracle's")
+    assert nbad <= 1e-5 * bits.size, nbad
+
+
 def test_bf16_layers_teacher_forced_vs_storage_oracle():
     """bf16 is the benchmarked dtype, and end to end a bf16 network is chaotic: a 1-ulp tie broken differently (different fp32 summation order)
     changes 1 % of the next layer's roundings, 18 % after two more layers, everything after six -- so NO independent implementation, however
