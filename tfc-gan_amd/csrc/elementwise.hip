@@ -457,23 +457,35 @@ tfc_act_pool2_bwd_kernel(const ActParams p, const T* __restrict__ dout, const T*
     }
     (isrow ? wrow[threadIdx.x] : wcol[threadIdx.x - TH]) = make_float4(w3[0], w3[1], w3[2], 0.f);
   }
-  for (int i = threadIdx.x; i < WH * WW * CVS; i += 256) {
-    const int cv = i % CVS, wp = i / CVS;
-    const int oy = oyb + wp / WW, ox = oxb + wp % WW;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo) {
-      const int opix = oy * p.Wo + ox;
-      v = *reinterpret_cast<const uint4*>(dn + (size_t)opix * p.o_pitch + (c0 / UE + cv) * UE);
-      if (p.drop_thresh24) {
+  // window staging, seven 16-byte units per thread and batch: all loads of a batch are requested (clamped address) before the first is stored -- one
+  // dependent load per loop iteration left a single request in flight per lane (the pattern that cost tfc_head_fwd_kernel half its time)
+  for (int b0 = 0; b0 < WH * WW * CVS; b0 += 7 * 256) {
+    uint4 wv[7];
+    int wopix[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int i = b0 + u * 256 + threadIdx.x;
+      const int cv = i % CVS, wp = i / CVS;
+      const int oy = oyb + wp / WW, ox = oxb + wp % WW;
+      const bool ok = i < WH * WW * CVS && oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo;
+      wopix[u] = ok ? oy * p.Wo + ox : -1;
+      wv[u] = *reinterpret_cast<const uint4*>(dn + (size_t)(ok ? wopix[u] : 0) * p.o_pitch + (c0 / UE + cv) * UE);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int i = b0 + u * 256 + threadIdx.x;
+      if (i >= WH * WW * CVS) continue;
+      uint4 v = wopix[u] >= 0 ? wv[u] : make_uint4(0, 0, 0, 0);
+      if (p.drop_thresh24 && wopix[u] >= 0) {
         float f[UE];
         unpack16<T>(v, f);
-        const uint32_t base = (uint32_t)(((size_t)n * nopix + opix) * p.C + c0 + cv * UE);
+        const uint32_t base = (uint32_t)(((size_t)n * nopix + wopix[u]) * p.C + c0 + (i % CVS) * UE);
 #pragma unroll
         for (int e = 0; e < UE; ++e) f[e] = tfc_keep(p.seed, base + e, p.drop_thresh24) ? f[e] * p.drop_scale : 0.f;
         v = pack16<T>(f);
       }
+      win[i] = v;
     }
-    win[i] = v;
   }
   float mean[UE], rstd[UE], mg[UE], mgx[UE];
 #pragma unroll
