@@ -35,3 +35,13 @@ for H, C in ((127, 128), (63, 256), (31, 512), (15, 512)):
     tb += b0 + b1 + b2
     tf += f0 + f1
 print(f"sum backward {tb:.1f} us, forward {tf:.1f} us")
+tu = 0.0
+for H, C in ((128, 64), (64, 128), (32, 256), (16, 512), (8, 512)):       # stride-1 blur of the up path: forward (+ InstanceNorm sums) and transpose
+    x = ops.View(torch.randn(N, H, H, C, device=DEV).to(torch.bfloat16), C)
+    y = ops.new_act(N, H, H, C, dt, DEV)
+    so = torch.zeros(N, C, 2, device=DEV)
+    f = t(lambda: ops.act_fwd(dt, x, y, stats=None, slope=1.0, pool=1, stats_out=so))
+    b = t(lambda: ops.act_bwd(dt, 0, x, None, N, H, H, C, y, stats=None, slope=1.0, pool=1))
+    print(f"{H:4d}^2 x {C:3d}: blur1 forward + sums {f:6.1f} us, transpose {b:6.1f} us")
+    tu += f + b
+print(f"sum blur1 {tu:.1f} us")

@@ -637,19 +637,25 @@ tfc_blur1_kernel(const ActParams p, const T* __restrict__ src, int src_pitch, T*
     float* t = isrow ? wrow + threadIdx.x * 8 : wcol + (threadIdx.x - TH) * 8;
     for (int j = 0; j < 5; ++j) t[j] = w5[j];
   }
-  for (int i = threadIdx.x; i < WH * WW * CVS; i += 256) {
-    const int cv = i % CVS, wp = i / CVS;
-    int y = ty0 - 2 + wp / WW, x = tx0 - 2 + wp % WW;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    bool ok;
-    if (!transpose) {                                              // reflect (1,2); positions beyond that carry zero weight
-      y = reflect_idx(y, p.H); x = reflect_idx(x, p.W);
-      ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
-    } else {
-      ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+  // window staging in batches of seven 16-byte units per thread, all loads of a batch requested (clamped address) before the first LDS store
+  // (as in tfc_act_pool2_bwd_kernel: one dependent load per loop iteration left a single request in flight per lane)
+  for (int b0 = 0; b0 < WH * WW * CVS; b0 += 7 * 256) {
+    uint4 wv[7];
+    bool wok[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int i = b0 + u * 256 + threadIdx.x;
+      const int cv = i % CVS, wp = i / CVS;
+      int y = ty0 - 2 + wp / WW, x = tx0 - 2 + wp % WW;
+      if (!transpose) { y = reflect_idx(y, p.H); x = reflect_idx(x, p.W); }   // forward: reflect (1,2); positions beyond that carry zero weight
+      wok[u] = i < WH * WW * CVS && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      wv[u] = *reinterpret_cast<const uint4*>(sn + (size_t)(wok[u] ? y * p.W + x : 0) * src_pitch + cv * UE);
     }
-    if (ok) v = *reinterpret_cast<const uint4*>(sn + (size_t)(y * p.W + x) * src_pitch + cv * UE);
-    win[i] = v;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int i = b0 + u * 256 + threadIdx.x;
+      if (i < WH * WW * CVS) win[i] = wok[u] ? wv[u] : make_uint4(0, 0, 0, 0);
+    }
   }
   __syncthreads();
   float a1[UE], a2[UE];
