@@ -886,6 +886,7 @@ __global__ void __launch_bounds__(256) tfc_snb_mv_kernel(const SnBatch b) {
   if ((K & 3) == 0) {                                            // 16-byte loads (K = Cin * 16; every row start is 16-byte aligned)
     const float4* W4 = reinterpret_cast<const float4*>(W);
     const float4* v4 = reinterpret_cast<const float4*>(v);
+#pragma unroll 8                                                   // eight row fragments in flight per lane (the adds stay in k order)
     for (int k = lane; k < (K >> 2); k += 64) { const float4 w = W4[k], x = v4[k]; a += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w; }
   } else {
     for (int k = lane; k < K; k += 64) a += W[k] * v[k];
@@ -917,6 +918,7 @@ __global__ void __launch_bounds__(256) tfc_snb_mtv_kernel(const SnBatch b, float
   const float* W = b.W[L];
   const int r1 = min(R, r0 + 32);
   float acc = 0.f;
+#pragma unroll 8
   for (int r = r0; r < r1; ++r) acc += W[(size_t)r * K + k] * ush[r - r0];
   b.t[L][(size_t)blockIdx.z * K + k] = acc;
 }
