@@ -327,3 +327,55 @@ def test_resize_plan_tables_reproduce_pil(h, w):
         box = (0, 0, w / 2, h) if half == 0 else (w / 2, 0, w, h)
         want = np.array(pil.crop(box).resize((out, out), Image.Resampling.BICUBIC))
         assert np.array_equal(got, want)
+
+
+def _one_rank_worker(port, out_path):
+    """one-rank gloo group on CPU: the collectives are skipped by default and issued under TFC_FORCE_COLLECTIVES=1 (the one-GPU rehearsal switch)"""
+    import json
+    import os
+    import torch
+    import torch.distributed as dist
+    from tfc_gan_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    named = {"a": torch.ones(1000), "b": torch.full((3000,), 2.0)}
+    flat = parallel.FlatParams(named, ["b", "a"], torch.device("cpu"))
+    flat.grad.fill_(3.0)
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    parallel.dist.all_reduce = counting
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["TFC_FORCE_COLLECTIVES"] = mode
+        calls["n"] = 0
+        red = parallel.BucketReducer(flat, bucket_bytes=4096)
+        for k in flat.order:
+            red.ready(k)
+        scale = red.finish()
+        res[mode] = {"active": parallel.collectives_active(), "calls": calls["n"], "scale": scale, "grad": float(flat.grad.sum())}
+    dist.destroy_process_group()
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+
+
+def test_collectives_switch_in_a_one_rank_group(tmp_path):
+    """parallel.collectives_active(): off in a one-rank group (nothing to exchange), on under TFC_FORCE_COLLECTIVES=1 -- then every bucket is all-reduced
+    (an identity) and finish() still returns 1 / world = 1"""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r.json")
+    p = mp.get_context("spawn").Process(target=_one_rank_worker, args=(port, out))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    res = json.load(open(out))
+    assert res["0"] == {"active": False, "calls": 0, "scale": 1.0, "grad": 3.0 * 4000}
+    assert res["1"]["active"] is True and res["1"]["calls"] == 2 and res["1"]["scale"] == 1.0 and res["1"]["grad"] == 3.0 * 4000
