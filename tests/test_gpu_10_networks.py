@@ -131,7 +131,9 @@ def _train_step_compare(golden, dtype, tol_loss, tol_grad):
 def test_train_step_fp32_vs_reference_golden(golden):
     # Gradient tolerance: ReLU / LeakyReLU masks are knife edges. At N=1 one max-magnitude element carries ~5e-3 of a gradient
     # tensor's L2 norm, so a single element with |xhat| < 1e-6 that lands on the other side of zero (summation order differs
-    # from torch's) moves every downstream gradient by ~1e-3 (measured run to run: 6e-4 .. 5e-3). Typical agreement is 6e-4.
+    # from torch's) moves every downstream gradient by ~1e-3 (round 2, with float atomics: 6e-4 .. 5e-3 from run to run). Since round 3 the engine's sums
+    # have a fixed order, so the number no longer moves from run to run (test_step_is_bit_deterministic_on_one_and_two_streams); the bound stays at the
+    # knife-edge scale because any legitimate change of a kernel's summation order lands somewhere in that range. Typical agreement is 6e-4.
     _train_step_compare(golden, torch.float32, 2e-4, 1e-2)
 
 
