@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tfc_gan_amd import ops
 DEV, dt, N = "cuda:0", ops.DT_BF16, 32
+torch.manual_seed(0)
 def t(f, n=20):
     for _ in range(3):
         f()
@@ -31,6 +32,11 @@ for H, C in ((127, 128), (63, 256), (31, 512), (15, 512)):
     f0 = t(lambda: ops.act_fwd(dt, x, y, stats=None, slope=1.0, pool=2))
     f1 = t(lambda: ops.act_fwd(dt, x, y, stats=st, slope=0.2, pool=2))
     mb = N * H * H * C * 2 / 1e6
+    ops.act_bwd(dt, 0, g, x, N, H, H, C, dx, stats=None, slope=0.2, pool=2)
+    c0 = dx.t.double().sum().item()
+    rs.zero_(); ops.act_bwd(dt, 1, g, x, N, H, H, C, None, stats=st, slope=0.2, pool=2, rstats=rs); c1 = rs.double().sum().item()
+    ops.act_bwd(dt, 2, g, x, N, H, H, C, dx, stats=st, slope=0.2, pool=2, rstats=rs); c2 = dx.t.double().abs().sum().item()
+    print(f"       checksums (bit-identity across builds): {c0!r} {c1!r} {c2!r}")
     print(f"{H:4d}^2 x {C:3d} ({mb:6.1f} MB tensor): bwd plain {b0:6.1f}  reduce {b1:6.1f}  apply {b2:6.1f} us | fwd blur {f0:6.1f}  norm+act+blur {f1:6.1f} us")
     tb += b0 + b1 + b2
     tf += f0 + f1
