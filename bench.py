@@ -176,7 +176,11 @@ def main():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
         sk.close()
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        except Exception as e:                                    # an environment problem, not a measurement: exit code 77
+            print("one-rank RCCL group unavailable:", repr(e), file=sys.stderr, flush=True)
+            raise SystemExit(77)
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     T.set_compute_dtype(cdt)

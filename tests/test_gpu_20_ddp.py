@@ -59,7 +59,10 @@ def test_two_stream_step_under_a_real_one_rank_rccl_group(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFC_FORCE_COLLECTIVES", "TFC_WGRAD_STREAM"):
         env.pop(k, None)
     subprocess.run([sys.executable, worker, plain, "plain"], check=True, env=env, timeout=300)
-    subprocess.run([sys.executable, worker, rccl, "rccl"], check=True, env=env, timeout=300)
+    r = subprocess.run([sys.executable, worker, rccl, "rccl"], env=env, timeout=300)
+    if r.returncode == 77:
+        pytest.skip("a one-rank RCCL process group cannot be created on this box (worker exit code 77)")
+    assert r.returncode == 0
     a, b = torch.load(plain, weights_only=True), torch.load(rccl, weights_only=True)
     assert int(b["collectives"]) >= 2 * (6 + 2), int(b["collectives"])          # 6 generator + 2 discriminator buckets per step (+ the loss averages)
     for k in ("g", "d", "gm", "dm", "sn", "loss"):

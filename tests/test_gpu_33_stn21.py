@@ -212,7 +212,10 @@ def test_stn21_step_under_a_real_one_rank_rccl_group(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFC_FORCE_COLLECTIVES", "TFC_TEST_RCCL1"):
         env.pop(k, None)
     subprocess.run([sys.executable, worker, one], check=True, env=env, timeout=600)
-    subprocess.run([sys.executable, worker, two], check=True, env=dict(env, TFC_TEST_RCCL1="1"), timeout=600)
+    r = subprocess.run([sys.executable, worker, two], env=dict(env, TFC_TEST_RCCL1="1"), timeout=600)
+    if r.returncode == 77:
+        pytest.skip("a one-rank RCCL process group cannot be created on this box (worker exit code 77)")
+    assert r.returncode == 0
     a, b = torch.load(one, weights_only=True), torch.load(two, weights_only=True)
     for k in ("losses", "gg", "dg", "g", "d"):
         assert torch.equal(a[k], b[k]), (k, (a[k].double() - b[k].double()).abs().max().item())

@@ -51,6 +51,8 @@ def test_bench_stn21_config_and_one_rank_rccl_mode_run():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    if out.returncode == 77:
+        pytest.skip("a one-rank RCCL process group cannot be created on this box (bench.py exit code 77)")
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["allreduce_backend"] == "nccl" and d["exposed_allreduce_ms"] > 0.0
